@@ -1,0 +1,101 @@
+"""ctypes binding of libfourq_amd.so (include/fourq_amd.h).  No fallback: a missing library or a
+missing GPU is an error, never a silent CPU path."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int, c_size_t, c_uint8, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
+
+OK, ERR_INVALID, ERR_NODEVICE, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
+DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
+
+u64p = POINTER(c_uint64)
+u8p = POINTER(c_uint8)
+
+# name -> (restype, argtypes); every symbol include/fourq_amd.h declares
+PROTOTYPES = {
+    "fourq_version": (c_int, []),
+    "fourq_strerror": (c_char_p, [c_int]),
+    "fourq_last_error": (c_char_p, [c_void_p]),
+    "fourq_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "fourq_ctx_destroy": (c_int, [c_void_p]),
+    "fourq_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "fourq_ctx_sync": (c_int, [c_void_p]),
+    "fourq_ctx_lanes": (c_int, [c_void_p, POINTER(c_size_t)]),
+    "fourq_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "fourq_dev_free": (c_int, [c_void_p, c_void_p]),
+    "fourq_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_table_windowed": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fourq_table_endo": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fourq_mul_endo_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_fixed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_fixed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_fixed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_fixed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_mixed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_mixed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_endo_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_windowed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_endo_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_windowed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_prim_words": (c_int, [c_int, POINTER(c_size_t), POINTER(c_size_t)]),
+    "fourq_prim_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
+}
+
+# enum fourq_prim
+PRIM = {
+    "FP_ADD": 0, "FP_SUB": 1, "FP_MUL": 2, "FP_SQR": 3, "FP_NEG": 4, "FP_INV": 5,
+    "FP2_ADD": 16, "FP2_SUB": 17, "FP2_MUL": 18, "FP2_SQR": 19, "FP2_NEG": 20, "FP2_CONJ": 21, "FP2_INV": 22,
+    "PT_DBL": 32, "PT_ADD": 33, "PT_ADD_CORE": 34, "PT_R1TOR2": 35, "PT_R1TOR3": 36, "PT_R2TOR4": 37,
+    "PT_TAU": 38, "PT_TAU_DUAL": 39, "PT_UPSILON": 40, "PT_CHI": 41, "PT_PHI": 42, "PT_PSI": 43,
+    "PT_ON_CURVE": 44, "PT_COFACTOR392": 45, "PT_R1TOAFFINE": 46,
+    "SC_DECOMPOSE": 64, "SC_RECODE": 65, "SC_WINDOWED": 66,
+}
+
+
+class FourQError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (no GPU is touched here)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime under the SONAME libfourq_amd.so also
+    # needs (libamdhip64.so.7).  One process must use ONE runtime: importing torch first makes the
+    # dynamic loader resolve our dependency to the copy torch already mapped, so device pointers,
+    # streams and RCCL communicators created by torch are valid in our calls.
+    if os.environ.get("FOURQ_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    if not os.path.exists(LIB_PATH):
+        raise FourQError(
+            "libfourq_amd.so is not built (%s). Run `python -m fourq_amd.build`; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc == OK:
+        return
+    lib = load()
+    msg = lib.fourq_strerror(rc).decode()
+    if ctx is not None and rc == ERR_HIP:
+        msg += ": " + lib.fourq_last_error(ctx).decode()
+    raise FourQError("fourq_amd: %s (code %d)" % (msg, rc))

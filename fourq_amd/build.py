@@ -1,0 +1,50 @@
+"""Builds libfourq_amd.so (HIP, gfx950 only) in-tree with hipcc.
+
+    python -m fourq_amd.build            # or: from fourq_amd.build import build_library
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
+git-ignored but travels to the GPU box with the tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC_DIR = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
+SOURCES = ["fourq_amd.hip"]
+HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the FourQ engine needs the ROCm toolchain to build")
+    return exe
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(SRC_DIR, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(os.path.normpath(d)) > built for d in deps)
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    """Compile the library if it is missing or older than its sources; returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB_PATH] + [os.path.join(SRC_DIR, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,277 @@
+// FourQ group law, endomorphisms and look-up tables on top of fp127.hip.h.
+//
+// Device counterparts of (bifurcation/fourq, impl/curve4q.py):
+//   PointOnCurve :23   AffineToR1 :100   R1toAffine :103   R1toR2 :109   R1toR3 :119   R2toR4 :129
+//   DBL :138   ADD_core :155   ADD :174   table_windowed :179   tau :258   tau_dual :269
+//   upsilon :282   chi :304   phi :318   psi :321   table_endo :385   the 392-cofactor chain :450-455
+//
+// Every function evaluates the SAME formula DAG as the reference, so that the un-normalised
+// projective outputs (X, Y, Z, Ta, Tb) are the same residues the reference returns (parity level
+// L2 of SURVEY.md section 8a28).  Only residue-preserving liberties are taken: 2*x is an addition
+// instead of a multiplication by (2,0); the constant 2d is precomputed; values that the reference
+// computes but never uses (chi's F) are not computed.
+#pragma once
+#include "fp127.hip.h"
+
+namespace fq {
+
+// ---- constants (canonical limbs, radix 2^26) ---------------------------------------------------
+// Generated from curve4q.py:9, :240-256 by tools/gen_constants.py; tests/test_gpu_primitives.py
+// checks every one of them through the primitive ABI.
+#include "constants.inc"
+
+// ---- point representations --------------------------------------------------------------------
+struct R1 {                  // (X, Y, Z, Ta, Tb), x = X/Z, y = Y/Z, T = Ta*Tb = XY/Z
+    Fe2<1> X, Y, Z;
+    Fe2<4> Ta;               // lazily bounded: DBL returns E (bound 4), ADD returns E (bound 3)
+    Fe2<2> Tb;
+};
+struct R2 {                  // (X+Y, Y-X, 2Z, 2dT): a table entry, stored tight
+    Fe2<1> N, D, E, F;
+};
+struct R2s {                 // a table entry after the sign selection (F possibly negated)
+    Fe2<1> N, D, E;
+    Fe2<2> F;
+};
+struct R3 {                  // (X+Y, Y-X, Z, T)
+    Fe2<2> N;
+    Fe2<3> D;
+    Fe2<1> E, F;
+};
+template <int BX, int BY, int BZ> struct Proj {   // (X, Y, Z) on E or on the isogenous curve
+    Fe2<BX> X;
+    Fe2<BY> Y;
+    Fe2<BZ> Z;
+};
+
+FQ_DEV R2s as_signed(const R2& t) {
+    R2s r; r.N = t.N; r.D = t.D; r.E = t.E; r.F = widen<2>(t.F); return r;
+}
+// selectpt(s, T[i], nT[i]) with nT = R2neg(T) = (D, N, E, -F)         curve4q.py:193-206
+// neg_mask = ~0 selects the negated entry, 0 the entry itself; branch-free.
+FQ_DEV R2s r2_apply_sign(const R2& t, u32 neg_mask) {
+    R2s r;
+    r.N = fe2_select(neg_mask, t.D, t.N);
+    r.D = fe2_select(neg_mask, t.N, t.D);
+    r.E = t.E;
+    r.F = fe2_select(neg_mask, fe2_neg(t.F), widen<2>(t.F));
+    return r;
+}
+
+FQ_DEV R1 affine_to_r1(const Fe2<1>& x, const Fe2<1>& y) {            // curve4q.py:100-101
+    R1 p; p.X = x; p.Y = y; p.Z = fe2_one(); p.Ta = widen<4>(x); p.Tb = widen<2>(y); return p;
+}
+FQ_DEV R2 r1_to_r2(const R1& p) {                                      // curve4q.py:109-116
+    R2 r;
+    r.N = fe2_carry(fe2_add(p.X, p.Y));
+    r.D = fe2_carry(fe2_sub(p.Y, p.X));
+    r.E = fe2_carry(fe2_dbl(p.Z));
+    r.F = fe2_mul(fe2_mul(p.Ta, p.Tb), fe2_two_d());
+    return r;
+}
+FQ_DEV R3 r1_to_r3(const R1& p) {                                      // curve4q.py:119-126
+    R3 r;
+    r.N = fe2_add(p.X, p.Y);
+    r.D = fe2_sub(p.Y, p.X);
+    r.E = p.Z;
+    r.F = fe2_mul(p.Ta, p.Tb);
+    return r;
+}
+FQ_DEV Proj<1, 1, 1> r2_to_r4(const R2s& t) {                          // curve4q.py:129-135 (the code, not the docstring)
+    Proj<1, 1, 1> r;
+    r.X = fe2_carry(fe2_sub(t.N, t.D));
+    r.Y = fe2_carry(fe2_add(t.D, t.N));
+    r.Z = t.E;
+    return r;
+}
+
+// R1/R4 -> R1                                                          curve4q.py:138-152
+FQ_DEV R1 dbl(const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
+    Fe2<1> A = fe2_sqr(X);
+    Fe2<1> B = fe2_sqr(Y);
+    Fe2<2> C = fe2_dbl(fe2_sqr(Z));
+    Fe2<2> D = fe2_add(A, B);
+    Fe2<4> E = fe2_sub(fe2_sqr(fe2_add(X, Y)), D);
+    Fe2<3> F = fe2_sub(B, A);
+    Fe2<6> G = fe2_sub(C, F);
+    R1 r;
+    r.X = fe2_mul(G, E);
+    r.Y = fe2_mul(F, D);
+    r.Z = fe2_mul(G, F);
+    r.Ta = E;
+    r.Tb = D;
+    return r;
+}
+FQ_DEV R1 dbl(const R1& p) { return dbl(p.X, p.Y, p.Z); }
+
+// R3 + R2 -> R1                                                        curve4q.py:155-171
+FQ_DEV R1 add_core(const R3& p, const R2s& q) {
+    Fe2<1> A = fe2_mul(p.D, q.D);
+    Fe2<1> B = fe2_mul(p.N, q.N);
+    Fe2<1> C = fe2_mul(q.F, p.F);
+    Fe2<1> D = fe2_mul(q.E, p.E);
+    Fe2<3> E = fe2_sub(B, A);
+    Fe2<3> F = fe2_sub(D, C);
+    Fe2<2> G = fe2_add(D, C);
+    Fe2<2> H = fe2_add(B, A);
+    R1 r;
+    r.X = fe2_mul(E, F);
+    r.Y = fe2_mul(G, H);
+    r.Z = fe2_mul(F, G);
+    r.Ta = widen<4>(E);
+    r.Tb = H;
+    return r;
+}
+FQ_DEV R1 add(const R1& p, const R2s& q) { return add_core(r1_to_r3(p), q); }   // curve4q.py:174-175
+
+// ---- endomorphisms ---------------------------------------------------------------------------
+FQ_DEV Proj<1, 2, 1> tau(const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {   // curve4q.py:258-267
+    Fe2<1> A = fe2_sqr(X);
+    Fe2<1> B = fe2_sqr(Y);
+    Fe2<2> C = fe2_add(A, B);
+    Fe2<3> D = fe2_sub(A, B);
+    Proj<1, 2, 1> r;
+    r.X = fe2_mul(D, fe2_mul(Y, fe2_mul(X, c_tau())));
+    r.Y = fe2_neg(fe2_mul(fe2_add(fe2_dbl(fe2_sqr(Z)), D), C));
+    r.Z = fe2_mul(D, C);
+    return r;
+}
+FQ_DEV R1 tau_dual(const Fe2<2>& X, const Fe2<2>& Y, const Fe2<2>& Z) {         // curve4q.py:269-280
+    Fe2<1> A = fe2_sqr(X);
+    Fe2<1> B = fe2_sqr(Y);
+    Fe2<2> C = fe2_add(A, B);
+    Fe2<3> Ta = fe2_sub(B, A);
+    Fe2<6> D = fe2_sub(fe2_dbl(fe2_sqr(Z)), Ta);
+    Fe2<1> Tb = fe2_mul(Y, fe2_mul(X, c_taudual()));
+    R1 r;
+    r.X = fe2_mul(C, Tb);
+    r.Y = fe2_mul(D, Ta);
+    r.Z = fe2_mul(D, C);
+    r.Ta = widen<4>(Ta);
+    r.Tb = widen<2>(Tb);
+    return r;
+}
+FQ_DEV Proj<2, 2, 2> upsilon(const Proj<1, 2, 1>& p) {                          // curve4q.py:282-302
+    Fe2<1> A = fe2_mul(p.Y, fe2_mul(p.X, c_phi<0>()));
+    Fe2<1> B = fe2_mul(p.Y, p.Z);
+    Fe2<1> C = fe2_sqr(p.Y);
+    Fe2<1> D = fe2_sqr(p.Z);
+    Fe2<1> F = fe2_sqr(D);
+    Fe2<1> G = fe2_sqr(B);
+    Fe2<1> H = fe2_sqr(C);
+    Fe2<1> I = fe2_mul(B, c_phi<1>());
+    Fe2<2> J = fe2_add(C, fe2_mul(D, c_phi<2>()));
+    Fe2<3> K = fe2_add(fe2_add(fe2_mul(G, c_phi<8>()), H), fe2_mul(F, c_phi<9>()));
+    Fe2<1> x2 = fe2_mul(fe2_sub(I, J), fe2_add(I, J));
+    Fe2<2> L = fe2_add(C, fe2_mul(D, c_phi<4>()));
+    Fe2<1> M = fe2_mul(B, c_phi<3>());
+    Fe2<1> Nn = fe2_mul(fe2_sub(L, M), fe2_add(L, M));
+    Fe2<3> y2 = fe2_add(fe2_add(H, fe2_mul(G, c_phi<6>())), fe2_mul(F, c_phi<7>()));
+    Proj<2, 2, 2> r;
+    r.X = fe2_conj(fe2_mul(fe2_mul(K, A), x2));
+    r.Y = fe2_conj(fe2_mul(y2, fe2_mul(fe2_mul(D, c_phi<5>()), Nn)));
+    r.Z = fe2_conj(fe2_mul(fe2_mul(K, B), Nn));
+    return r;
+}
+FQ_DEV Proj<1, 1, 1> chi(const Proj<1, 2, 1>& p) {                              // curve4q.py:304-316
+    Fe2<2> A = fe2_conj(p.X);
+    Fe2<3> B = fe2_conj(p.Y);
+    Fe2<1> C = fe2_sqr(fe2_conj(p.Z));
+    Fe2<1> D = fe2_sqr(A);
+    Fe2<1> G = fe2_mul(B, fe2_add(D, fe2_mul(C, c_psi<2>())));
+    Fe2<3> H = fe2_neg(fe2_add(D, fe2_mul(C, c_psi<4>())));
+    Proj<1, 1, 1> r;
+    r.X = fe2_mul(H, fe2_mul(fe2_mul(A, c_psi<1>()), C));
+    r.Y = fe2_mul(fe2_add(D, fe2_mul(C, c_psi<3>())), G);
+    r.Z = fe2_mul(H, G);
+    return r;
+}
+FQ_DEV R1 phi(const R1& p) {                                                    // curve4q.py:318-319
+    Proj<2, 2, 2> u = upsilon(tau(p.X, p.Y, p.Z));
+    return tau_dual(u.X, u.Y, u.Z);
+}
+FQ_DEV R1 psi(const R1& p) {                                                    // curve4q.py:321-322
+    Proj<1, 1, 1> c = chi(tau(p.X, p.Y, p.Z));
+    return tau_dual(widen<2>(c.X), widen<2>(c.Y), widen<2>(c.Z));
+}
+
+// ---- membership, cofactor clearing, normalisation (the DH wrapper) ---------------------------
+FQ_DEV bool point_on_curve(const Fe2<1>& x, const Fe2<1>& y) {                  // curve4q.py:23-29
+    Fe2<1> x2 = fe2_sqr(x), y2 = fe2_sqr(y);
+    Fe2<3> lhs = fe2_sub(y2, x2);
+    Fe2<2> rhs = fe2_add(fe2_one(), fe2_mul(y2, fe2_mul(x2, c_d())));
+    return fe2_equal(lhs, rhs);
+}
+FQ_DEV R1 clear_cofactor_392(const Fe2<1>& x, const Fe2<1>& y) {                // curve4q.py:450-455
+    R1 p0 = affine_to_r1(x, y);
+    R2s t0 = as_signed(r1_to_r2(p0));
+    R1 q = add(dbl(p0), t0);                  // 3P
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) q = dbl(q);   // 48P
+    q = add(q, t0);                           // 49P
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) q = dbl(q);   // 392P
+    return q;
+}
+FQ_DEV void r1_to_affine(const R1& p, Fe2<1>& x, Fe2<1>& y) {                   // curve4q.py:103-106
+    Fe2<1> zi = fe2_inv(p.Z);
+    x = fe2_mul(p.X, zi);
+    y = fe2_mul(p.Y, zi);
+}
+
+// ---- memory forms ------------------------------------------------------------------------------
+// C-ABI form: 128-bit little-endian words (fields packed, canonical on output).
+FQ_DEV Fe2<1> load_fe2(const u64* w) {
+    Fe2<1> r; r.re = fe_unpack(w[0], w[1]); r.im = fe_unpack(w[2], w[3]); return r;
+}
+template <int B> FQ_DEV void store_fe2(u64* w, const Fe2<B>& a) {
+    fe_canon(a.re, w[0], w[1]); fe_canon(a.im, w[2], w[3]);
+}
+FQ_DEV R1 load_r1(const u64* w) {
+    R1 p;
+    p.X = load_fe2(w); p.Y = load_fe2(w + 4); p.Z = load_fe2(w + 8);
+    p.Ta = widen<4>(load_fe2(w + 12)); p.Tb = widen<2>(load_fe2(w + 16));
+    return p;
+}
+FQ_DEV void store_r1(u64* w, const R1& p) {
+    store_fe2(w, p.X); store_fe2(w + 4, p.Y); store_fe2(w + 8, p.Z); store_fe2(w + 12, p.Ta); store_fe2(w + 16, p.Tb);
+}
+FQ_DEV R2 load_r2_packed(const u64* w) {
+    R2 t; t.N = load_fe2(w); t.D = load_fe2(w + 4); t.E = load_fe2(w + 8); t.F = load_fe2(w + 12); return t;
+}
+FQ_DEV void store_r2_packed(u64* w, const R2& t) {
+    store_fe2(w, t.N); store_fe2(w + 4, t.D); store_fe2(w + 8, t.E); store_fe2(w + 12, t.F);
+}
+
+// Working form of a table entry: 40 limbs (tight) = 10 x uint4, in HBM scratch or LDS.
+constexpr int R2_LIMBS = 40;
+template <typename P> FQ_DEV R2 load_r2_limbs(const P* src) {   // src: uint4-aligned u32 pointer
+    R2 t;
+    u32 v[R2_LIMBS];
+#pragma unroll
+    for (int i = 0; i < R2_LIMBS / 4; i++) {
+        uint4 q = reinterpret_cast<const uint4*>(src)[i];
+        v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+    Fe2<1>* f = &t.N;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { f[k].re.l[i] = v[10 * k + i]; f[k].im.l[i] = v[10 * k + 5 + i]; }
+    }
+    return t;
+}
+template <typename P> FQ_DEV void store_r2_limbs(P* dst, const R2& t) {
+    u32 v[R2_LIMBS];
+    const Fe2<1>* f = &t.N;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { v[10 * k + i] = f[k].re.l[i]; v[10 * k + 5 + i] = f[k].im.l[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < R2_LIMBS / 4; i++)
+        reinterpret_cast<uint4*>(dst)[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
+}  // namespace fq

@@ -1,0 +1,696 @@
+// libfourq_amd.so -- HIP kernels and the C ABI declared in include/fourq_amd.h.
+//
+// Kernel design (gfx950): one wavefront lane owns one (scalar, point) pair for the whole scalar
+// multiplication.  Lanes never communicate; a workgroup is 256 lanes; the grid is sized to the
+// number of resident lanes and strides over the batch, so per-lane table scratch is sized by
+// residency, not by batch size.
+//
+//   variable base : the lane builds its own 8-entry R2 table (table_endo / table_windowed) into a
+//                   1.5 KiB slot of HBM scratch (one 160-byte line group per entry), then each
+//                   ladder step gathers the entry its digit selects (wavefront-level gather, one
+//                   entry per lane) while the doubling runs.
+//   fixed base    : the 8-entry table is staged once per workgroup into LDS (padded to dodge bank
+//                   conflicts) and gathered from there.
+//   selection     : the sign of a digit is applied branch-free (mask selects); the table index is
+//                   a per-lane address, as in the reference (curve4q.py:232, :440).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/fourq_amd.h"
+#include "curve.hip.h"
+#include "recode.hip.h"
+
+using namespace fq;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int SLOT_U32 = 384;          // per-lane scratch: 8 table entries (320) + P.xyz (30) + Q.xyz (30), padded
+constexpr int SLOT_P = 320, SLOT_Q = 352;
+constexpr int LDS_ENTRY_U32 = 44;      // 40 limbs + 4 pad: entry k starts at bank 44k mod 64 -> conflict-free b128 gathers
+
+enum Algo { ENDO = 0, WINDOWED = 1 };
+
+struct LadderArgs {
+    const u64* scalars;    // n x 4
+    const u64* points;     // variable base: n x 20 (R1) ; DH: n x 8 (affine) ; else unused
+    u64* out;              // n x 20 (R1) or n x 8 (affine, DH)
+    uint8_t* status;       // DH only
+    const u32* index;      // optional: element ids to process (mixed batches); NULL = identity
+    const u32* table;      // fixed base: 8 x 40 limbs (global), staged to LDS
+    u32* scratch;          // variable base: SLOT_U32 per resident lane
+    u32 n;
+};
+
+// ---- small helpers -----------------------------------------------------------------------------
+FQ_DEV void store_xyz(u32* dst, const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
+    const Fe2<1>* f[3] = { &X, &Y, &Z };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { dst[10 * k + i] = f[k]->re.l[i]; dst[10 * k + 5 + i] = f[k]->im.l[i]; }
+    }
+}
+FQ_DEV void load_xyz(const u32* src, Fe2<1>& X, Fe2<1>& Y, Fe2<1>& Z) {
+    Fe2<1>* f[3] = { &X, &Y, &Z };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { f[k]->re.l[i] = src[10 * k + i]; f[k]->im.l[i] = src[10 * k + 5 + i]; }
+    }
+}
+FQ_DEV R3 r3_tight(const R3& p) { return p; }
+
+// T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                       curve4q.py:179-185
+FQ_DEV void build_table_windowed(const R1& P, u32* tbl) {
+    R3 twoP = r1_to_r3(dbl(P));
+    R2 t = r1_to_r2(P);
+    store_r2_limbs(tbl, t);
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+        t = r1_to_r2(add_core(twoP, as_signed(t)));
+        store_r2_limbs(tbl + i * R2_LIMBS, t);
+    }
+}
+
+// T[k] = P + k0*phi(P) + k1*psi(P) + k2*psi(phi(P)), built in the reference's order      curve4q.py:385-403
+//   step 0: Q = phi(P) -> T[1] = Q + T[0]
+//   step 1: R = psi(P) -> T[2] = R + T[0], T[3] = R + T[1]
+//   step 2: S = psi(Q) -> T[4..7] = S + T[0..3]
+// tau and tau_dual are shared by the three steps (one code instance each): the working points P and
+// Q are parked in the lane's scratch slot so that they do not pin 60 VGPRs across the endomorphisms.
+FQ_DEV void build_table_endo(const R1& P, u32* slot) {
+    store_r2_limbs(slot, r1_to_r2(P));
+    store_xyz(slot + SLOT_P, P.X, P.Y, P.Z);
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        Fe2<1> X, Y, Z;
+        load_xyz(slot + (step == 2 ? SLOT_Q : SLOT_P), X, Y, Z);
+        Proj<1, 2, 1> t = tau(X, Y, Z);
+        Proj<2, 2, 2> u;
+        if (step == 0) {
+            u = upsilon(t);
+        } else {
+            Proj<1, 1, 1> c = chi(t);
+            u.X = widen<2>(c.X); u.Y = widen<2>(c.Y); u.Z = widen<2>(c.Z);
+        }
+        R1 V = tau_dual(u.X, u.Y, u.Z);
+        if (step == 0) store_xyz(slot + SLOT_Q, V.X, V.Y, V.Z);
+        R3 V3 = r1_to_r3(V);
+        int half = 1 << step;
+#pragma unroll 1
+        for (int m = 0; m < half; m++) {
+            R2 base = load_r2_limbs(slot + m * R2_LIMBS);
+            store_r2_limbs(slot + (half + m) * R2_LIMBS, r1_to_r2(add_core(V3, as_signed(base))));
+        }
+    }
+}
+
+// ---- the ladders -------------------------------------------------------------------------------
+template <typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
+    R2 t = load_r2_limbs(tbl + (e.top & 7) * stride);
+    Proj<1, 1, 1> q4 = r2_to_r4(as_signed(t));        // s[64] = 1: the entry itself
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+#pragma unroll 1
+    for (int i = 63; i >= 0; i--) {
+        t = load_r2_limbs(tbl + endo_digit(e, i) * stride);
+        Q = dbl(Q.X, Q.Y, Q.Z);
+        Q = add(Q, r2_apply_sign(t, endo_neg_mask(e, i)));
+    }
+    return Q;
+}
+template <typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
+    u32 code = win_top_code(w);
+    R2 t = load_r2_limbs(tbl + (code & 7) * stride);
+    Proj<1, 1, 1> q4 = r2_to_r4(r2_apply_sign(t, (code >> 3) - 1u));
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+#pragma unroll 1
+    for (int i = 61; i >= 0; i--) {
+        code = win_code_from_window(win_window(w, i));
+        t = load_r2_limbs(tbl + (code & 7) * stride);
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) Q = dbl(Q.X, Q.Y, Q.Z);
+        Q = add(Q, r2_apply_sign(t, (code >> 3) - 1u));
+    }
+    return Q;
+}
+
+FQ_DEV void load_scalar(const u64* p, u64 m[4]) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    m[0] = (u64)a.x | ((u64)a.y << 32); m[1] = (u64)a.z | ((u64)a.w << 32);
+    m[2] = (u64)b.x | ((u64)b.y << 32); m[3] = (u64)b.z | ((u64)b.w << 32);
+}
+
+// ALGO: ENDO / WINDOWED.  FIXED: shared table in LDS.  DH: affine in, cofactor clearing, affine out + status.
+template <int ALGO, bool FIXED, bool DH>
+__global__ __launch_bounds__(BLOCK) void ladder_kernel(LadderArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 lds_table[FIXED ? 8 * LDS_ENTRY_U32 : 4];
+    if (FIXED) {
+        for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
+            lds_table[(i / R2_LIMBS) * LDS_ENTRY_U32 + (i % R2_LIMBS)] = a.table[i];
+        __syncthreads();
+    }
+    const u32 lane_slot = blockIdx.x * BLOCK + threadIdx.x;
+    const u32 lanes = gridDim.x * BLOCK;
+    u32* slot = FIXED ? nullptr : a.scratch + (size_t)lane_slot * SLOT_U32;
+    const u32 n_round = (a.n + BLOCK - 1) / BLOCK * BLOCK;
+#pragma unroll 1
+    for (u32 it = lane_slot; it < n_round; it += lanes) {
+        const bool live = it < a.n;
+        const u32 pos = live ? it : a.n - 1;              // idle tail lanes redo the last element, store nothing
+        const u32 id = a.index ? a.index[pos] : pos;
+        u64 m[4];
+        load_scalar(a.scalars + 4 * (size_t)id, m);
+
+        uint8_t st = FOURQ_DH_OK;
+        R1 P;
+        if (DH) {
+            Fe2<1> x = load_fe2(a.points + 8 * (size_t)id), y = load_fe2(a.points + 8 * (size_t)id + 4);
+            if (!point_on_curve(x, y)) st = FOURQ_DH_NOT_ON_CURVE;     // keep going branch-free; masked at the end
+            if (!FIXED) P = clear_cofactor_392(x, y);                   // with a table the reference discards [392]P (curve4q.py:209)
+        } else if (!FIXED) {
+            P = load_r1(a.points + 20 * (size_t)id);
+        }
+        if (!FIXED) {
+            if (ALGO == ENDO) build_table_endo(P, slot); else build_table_windowed(P, slot);
+        }
+        R1 Q;
+        if (ALGO == ENDO) {
+            u64 v[4];
+            decompose(m, v);
+            EndoDigits e = recode(v);
+            Q = FIXED ? ladder_endo(e, lds_table, LDS_ENTRY_U32) : ladder_endo(e, slot, R2_LIMBS);
+        } else {
+            WinScalar w = win_reduce(m);
+            Q = FIXED ? ladder_windowed(w, lds_table, LDS_ENTRY_U32) : ladder_windowed(w, slot, R2_LIMBS);
+        }
+        if (DH) {
+            Fe2<1> ax, ay;
+            r1_to_affine(Q, ax, ay);
+            u64 o[8];
+            store_fe2(o, ax); store_fe2(o + 4, ay);
+            bool neutral = (o[0] | o[1] | o[2] | o[3] | o[5] | o[6] | o[7]) == 0 && o[4] == 1;   // (Ox, Oy) = ((0,0),(1,0))
+            if (st == FOURQ_DH_OK && neutral) st = FOURQ_DH_NEUTRAL;
+            if (live) {
+                uint4* dst = reinterpret_cast<uint4*>(a.out + 8 * (size_t)id);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    u64 lo = st ? 0 : o[2 * k], hi = st ? 0 : o[2 * k + 1];
+                    dst[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+                }
+                a.status[id] = st;
+            }
+        } else if (live) {
+            u64 o[20];
+            store_r1(o, Q);
+            uint4* dst = reinterpret_cast<uint4*>(a.out + 20 * (size_t)id);
+#pragma unroll
+            for (int k = 0; k < 10; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
+        }
+    }
+}
+
+// packed table (8 x 16 words) -> working limbs (8 x 40 u32)
+__global__ void table_unpack_kernel(const u64* packed, u32* limbs) {
+    int k = threadIdx.x;
+    if (k < 8) store_r2_limbs(limbs + k * R2_LIMBS, load_r2_packed(packed + 16 * k));
+}
+// working limbs of one lane's scratch slot -> packed table
+__global__ void table_build_kernel(int algo, const u64* p_r1, u32* scratch, u64* packed) {
+    if (threadIdx.x != 0) return;
+    R1 P = load_r1(p_r1);
+    if (algo == ENDO) build_table_endo(P, scratch); else build_table_windowed(P, scratch);
+    for (int k = 0; k < 8; k++) store_r2_packed(packed + 16 * k, load_r2_limbs(scratch + k * R2_LIMBS));
+}
+// stable partition of element ids by flag for mixed batches: idx[0..nf) fixed, idx[n-nv..n) variable
+__global__ void partition_kernel(const uint8_t* flags, u32 n, u32* idx, u32* counters) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i] == 0) idx[atomicAdd(&counters[0], 1u)] = i;
+    else idx[n - 1 - atomicAdd(&counters[1], 1u)] = i;
+}
+
+// ---- primitives ----------------------------------------------------------------------------------
+FQ_DEV Fe<1> ld_fe(const u64* w) { return fe_unpack(w[0], w[1]); }
+template <int B> FQ_DEV void st_fe(u64* w, const Fe<B>& a) { fe_canon(a, w[0], w[1]); }
+template <int BX, int BY, int BZ> FQ_DEV void st_proj(u64* w, const Proj<BX, BY, BZ>& p) {
+    store_fe2(w, p.X); store_fe2(w + 4, p.Y); store_fe2(w + 8, p.Z);
+}
+FQ_DEV R2s ld_r2s(const u64* w) { return as_signed(load_r2_packed(w)); }
+
+__global__ __launch_bounds__(64) void prim_kernel(int op, const u64* in, u64* out, u32 n, u32 iw, u32 ow) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64* x = in + (size_t)i * iw;
+    u64* y = out + (size_t)i * ow;
+    switch (op) {
+    case FOURQ_FP_ADD: st_fe(y, fe_add(ld_fe(x), ld_fe(x + 2))); break;
+    case FOURQ_FP_SUB: st_fe(y, fe_sub(ld_fe(x), ld_fe(x + 2))); break;
+    case FOURQ_FP_MUL: st_fe(y, fe_mul(ld_fe(x), ld_fe(x + 2))); break;
+    case FOURQ_FP_SQR: st_fe(y, fe_sqr(ld_fe(x))); break;
+    case FOURQ_FP_NEG: st_fe(y, fe_neg(ld_fe(x))); break;
+    case FOURQ_FP_INV: st_fe(y, fe_inv(fe_carry(ld_fe(x)))); break;
+    case FOURQ_FP2_ADD: store_fe2(y, fe2_add(load_fe2(x), load_fe2(x + 4))); break;
+    case FOURQ_FP2_SUB: store_fe2(y, fe2_sub(load_fe2(x), load_fe2(x + 4))); break;
+    case FOURQ_FP2_MUL: store_fe2(y, fe2_mul(load_fe2(x), load_fe2(x + 4))); break;
+    case FOURQ_FP2_SQR: store_fe2(y, fe2_sqr(load_fe2(x))); break;
+    case FOURQ_FP2_NEG: store_fe2(y, fe2_neg(load_fe2(x))); break;
+    case FOURQ_FP2_CONJ: store_fe2(y, fe2_conj(load_fe2(x))); break;
+    case FOURQ_FP2_INV: store_fe2(y, fe2_inv(load_fe2(x))); break;
+    case FOURQ_PT_DBL: store_r1(y, dbl(load_r1(x))); break;
+    case FOURQ_PT_ADD: store_r1(y, add(load_r1(x), ld_r2s(x + 20))); break;
+    case FOURQ_PT_ADD_CORE: {
+        R2 p = load_r2_packed(x);
+        R3 p3; p3.N = widen<2>(p.N); p3.D = widen<3>(p.D); p3.E = p.E; p3.F = p.F;
+        store_r1(y, add_core(p3, ld_r2s(x + 16)));
+        break;
+    }
+    case FOURQ_PT_R1TOR2: store_r2_packed(y, r1_to_r2(load_r1(x))); break;
+    case FOURQ_PT_R1TOR3: {
+        R3 r = r1_to_r3(load_r1(x));
+        store_fe2(y, r.N); store_fe2(y + 4, r.D); store_fe2(y + 8, r.E); store_fe2(y + 12, r.F);
+        break;
+    }
+    case FOURQ_PT_R2TOR4: st_proj(y, r2_to_r4(ld_r2s(x))); break;
+    case FOURQ_PT_TAU: st_proj(y, tau(load_fe2(x), load_fe2(x + 4), load_fe2(x + 8))); break;
+    case FOURQ_PT_TAU_DUAL:
+        store_r1(y, tau_dual(widen<2>(load_fe2(x)), widen<2>(load_fe2(x + 4)), widen<2>(load_fe2(x + 8))));
+        break;
+    case FOURQ_PT_UPSILON:
+    case FOURQ_PT_CHI: {
+        Proj<1, 2, 1> p; p.X = load_fe2(x); p.Y = widen<2>(load_fe2(x + 4)); p.Z = load_fe2(x + 8);
+        if (op == FOURQ_PT_UPSILON) st_proj(y, upsilon(p)); else st_proj(y, chi(p));
+        break;
+    }
+    case FOURQ_PT_PHI: store_r1(y, phi(load_r1(x))); break;
+    case FOURQ_PT_PSI: store_r1(y, psi(load_r1(x))); break;
+    case FOURQ_PT_ON_CURVE: y[0] = point_on_curve(load_fe2(x), load_fe2(x + 4)) ? 1 : 0; break;
+    case FOURQ_PT_COFACTOR392: store_r1(y, clear_cofactor_392(load_fe2(x), load_fe2(x + 4))); break;
+    case FOURQ_PT_R1TOAFFINE: {
+        Fe2<1> ax, ay;
+        r1_to_affine(load_r1(x), ax, ay);
+        store_fe2(y, ax); store_fe2(y + 4, ay);
+        break;
+    }
+    case FOURQ_SC_DECOMPOSE: {
+        u64 m[4] = { x[0], x[1], x[2], x[3] }, v[4];
+        decompose(m, v);
+        y[0] = v[0]; y[1] = v[1]; y[2] = v[2]; y[3] = v[3];
+        break;
+    }
+    case FOURQ_SC_RECODE: {
+        u64 v[4] = { x[0], x[1], x[2], x[3] };
+        EndoDigits e = recode(v);
+        y[0] = e.sign; y[1] = e.d[0]; y[2] = e.d[1]; y[3] = e.d[2]; y[4] = e.top;
+        break;
+    }
+    case FOURQ_SC_WINDOWED: {
+        u64 m[4] = { x[0], x[1], x[2], x[3] };
+        WinScalar w = win_reduce(m);
+        uint8_t* b = reinterpret_cast<uint8_t*>(y);
+        for (int k = 0; k < 62; k++) b[k] = (uint8_t)win_code_from_window(win_window(w, k));
+        b[62] = (uint8_t)win_top_code(w);
+        b[63] = 0;
+        break;
+    }
+    default: break;
+    }
+}
+
+struct PrimShape { int op; size_t in_words, out_words; };
+const PrimShape PRIMS[] = {
+    { FOURQ_FP_ADD, 4, 2 }, { FOURQ_FP_SUB, 4, 2 }, { FOURQ_FP_MUL, 4, 2 }, { FOURQ_FP_SQR, 4, 2 }, { FOURQ_FP_NEG, 4, 2 }, { FOURQ_FP_INV, 4, 2 },
+    { FOURQ_FP2_ADD, 8, 4 }, { FOURQ_FP2_SUB, 8, 4 }, { FOURQ_FP2_MUL, 8, 4 }, { FOURQ_FP2_SQR, 8, 4 }, { FOURQ_FP2_NEG, 8, 4 },
+    { FOURQ_FP2_CONJ, 8, 4 }, { FOURQ_FP2_INV, 8, 4 },
+    { FOURQ_PT_DBL, 20, 20 }, { FOURQ_PT_ADD, 36, 20 }, { FOURQ_PT_ADD_CORE, 32, 20 }, { FOURQ_PT_R1TOR2, 20, 16 },
+    { FOURQ_PT_R1TOR3, 20, 16 }, { FOURQ_PT_R2TOR4, 16, 12 }, { FOURQ_PT_TAU, 12, 12 }, { FOURQ_PT_TAU_DUAL, 12, 20 },
+    { FOURQ_PT_UPSILON, 12, 12 }, { FOURQ_PT_CHI, 12, 12 }, { FOURQ_PT_PHI, 20, 20 }, { FOURQ_PT_PSI, 20, 20 },
+    { FOURQ_PT_ON_CURVE, 8, 1 }, { FOURQ_PT_COFACTOR392, 8, 20 }, { FOURQ_PT_R1TOAFFINE, 20, 8 },
+    { FOURQ_SC_DECOMPOSE, 4, 4 }, { FOURQ_SC_RECODE, 4, 5 }, { FOURQ_SC_WINDOWED, 4, 8 },
+};
+const PrimShape* find_prim(int op) {
+    for (const PrimShape& p : PRIMS) if (p.op == op) return &p;
+    return nullptr;
+}
+
+}  // namespace
+
+// ====================================================================================== C ABI
+struct fourq_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int cus = 0;
+    size_t lanes = 0;              // resident lanes the ladder kernels are launched with
+    u32* scratch = nullptr;        // lanes x SLOT_U32
+    u32* table_limbs = nullptr;    // 8 x 40
+    u64* table_packed = nullptr;   // 128 words
+    u32* part_counters = nullptr;  // 2
+    void* stage = nullptr;         // staging for the host-pointer API
+    size_t stage_bytes = 0;
+    char err[256] = { 0 };
+};
+
+namespace {
+
+int fail(fourq_ctx* c, hipError_t e, const char* what) {
+    if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? FOURQ_ERR_NOMEM : FOURQ_ERR_HIP;
+}
+#define HIP_TRY(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((c), e_, #call); } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int ensure_stage(fourq_ctx* c, size_t bytes) {
+    if (bytes <= c->stage_bytes) return FOURQ_OK;
+    if (c->stage) { HIP_TRY(c, hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
+    size_t want = bytes + bytes / 4;
+    HIP_TRY(c, hipMalloc(&c->stage, want));
+    c->stage_bytes = want;
+    return FOURQ_OK;
+}
+
+template <int ALGO, bool FIXED, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs a) {
+    if (a.n == 0) return FOURQ_OK;
+    size_t blocks_needed = ((size_t)a.n + BLOCK - 1) / BLOCK;
+    size_t blocks_max = c->lanes / BLOCK;
+    unsigned grid = (unsigned)(blocks_needed < blocks_max ? blocks_needed : blocks_max);
+    a.scratch = c->scratch;
+    a.table = c->table_limbs;
+    hipLaunchKernelGGL((ladder_kernel<ALGO, FIXED, DH>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+
+int stage_table(fourq_ctx* c, const uint64_t* table_host) {
+    HIP_TRY(c, hipMemcpyAsync(c->table_packed, table_host, FOURQ_TABLE_WORDS * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(table_unpack_kernel, dim3(1), dim3(64), 0, c->stream, c->table_packed, c->table_limbs);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+
+int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
+            const u32* index, size_t n) {
+    if (!c || !scalars || !out || (!points && !table) || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    LadderArgs a = {};
+    a.scalars = scalars; a.points = points; a.out = out; a.index = index; a.n = (u32)n;
+    if (points) return algo == ENDO ? launch_ladder<ENDO, false, false>(c, a) : launch_ladder<WINDOWED, false, false>(c, a);
+    int rc = stage_table(c, table);
+    if (rc) return rc;
+    return algo == ENDO ? launch_ladder<ENDO, true, false>(c, a) : launch_ladder<WINDOWED, true, false>(c, a);
+}
+
+int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
+           uint8_t* status, size_t n) {
+    if (!c || !scalars || !points || !out || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    LadderArgs a = {};
+    a.scalars = scalars; a.points = points; a.out = out; a.status = status; a.n = (u32)n;
+    if (!table) return algo == ENDO ? launch_ladder<ENDO, false, true>(c, a) : launch_ladder<WINDOWED, false, true>(c, a);
+    int rc = stage_table(c, table);
+    if (rc) return rc;
+    return algo == ENDO ? launch_ladder<ENDO, true, true>(c, a) : launch_ladder<WINDOWED, true, true>(c, a);
+}
+
+// host-pointer wrappers: one staging buffer carved into [scalars | points | out | status]
+int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out, size_t n) {
+    if (!c || !scalars || !out || (!points && !table)) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    size_t sb = n * 32, pb = points ? n * 160 : 0, ob = n * 160;
+    int rc = ensure_stage(c, sb + pb + ob);
+    if (rc) return rc;
+    char* base = (char*)c->stage;
+    HIP_TRY(c, hipMemcpyAsync(base, scalars, sb, hipMemcpyHostToDevice, c->stream));
+    if (points) HIP_TRY(c, hipMemcpyAsync(base + sb, points, pb, hipMemcpyHostToDevice, c->stream));
+    rc = mul_dev(c, algo, (const uint64_t*)base, points ? (const uint64_t*)(base + sb) : nullptr, table, (uint64_t*)(base + sb + pb), nullptr, n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, base + sb + pb, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
+            uint8_t* status, size_t n) {
+    if (!c || !scalars || !points || !out || !status) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    size_t sb = n * 32, pb = n * 64, ob = n * 64, tb = (n + 15) / 16 * 16;
+    int rc = ensure_stage(c, sb + pb + ob + tb);
+    if (rc) return rc;
+    char* base = (char*)c->stage;
+    HIP_TRY(c, hipMemcpyAsync(base, scalars, sb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + sb, points, pb, hipMemcpyHostToDevice, c->stream));
+    rc = dh_dev(c, algo, (const uint64_t*)base, (const uint64_t*)(base + sb), table, (uint64_t*)(base + sb + pb),
+                (uint8_t*)(base + sb + pb + ob), n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, base + sb + pb, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(status, base + sb + pb + ob, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+
+int table_host(fourq_ctx* c, int algo, const uint64_t* p_r1, uint64_t* table) {
+    if (!c || !p_r1 || !table) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    int rc = ensure_stage(c, 160);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->stage, p_r1, 160, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(table_build_kernel, dim3(1), dim3(64), 0, c->stream, algo, (const u64*)c->stage, c->scratch, c->table_packed);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(table, c->table_packed, FOURQ_TABLE_WORDS * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define FQ_API __attribute__((visibility("default")))
+
+FQ_API int fourq_version(void) { return 100; }
+
+FQ_API const char* fourq_strerror(int code) {
+    switch (code) {
+    case FOURQ_OK: return "ok";
+    case FOURQ_ERR_INVALID: return "invalid argument";
+    case FOURQ_ERR_NODEVICE: return "no usable gfx950 HIP device";
+    case FOURQ_ERR_NOMEM: return "out of memory";
+    case FOURQ_ERR_HIP: return "HIP runtime error";
+    default: return "unknown error";
+    }
+}
+FQ_API const char* fourq_last_error(const fourq_ctx* ctx) { return ctx ? ctx->err : "no context"; }
+
+FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
+    if (!out) return FOURQ_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return FOURQ_ERR_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return FOURQ_ERR_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FOURQ_ERR_NODEVICE;   // the code object is gfx950 only
+    fourq_ctx* c = new (std::nothrow) fourq_ctx();
+    if (!c) return FOURQ_ERR_NOMEM;
+    c->device = device;
+    c->cus = prop.multiProcessorCount;
+    DeviceGuard g(device);
+    int rc = FOURQ_OK;
+    do {
+        if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        c->stream = c->own_stream;
+        // resident blocks per CU: the minimum over the variable-base kernels (they own the scratch)
+        int occ = 8, o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<ENDO, false, false>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<WINDOWED, false, true>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
+        if (const char* env = getenv("FOURQ_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) occ = v; }
+        c->lanes = (size_t)c->cus * occ * BLOCK;
+        if (hipMalloc(&c->scratch, c->lanes * SLOT_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->part_counters, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+    } while (0);
+    if (rc) { fourq_ctx_destroy(c); return rc; }
+    *out = c;
+    return FOURQ_OK;
+}
+
+FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
+    if (!c) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->table_limbs) (void)hipFree(c->table_limbs);
+    if (c->table_packed) (void)hipFree(c->table_packed);
+    if (c->part_counters) (void)hipFree(c->part_counters);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return FOURQ_OK;
+}
+
+FQ_API int fourq_ctx_set_stream(fourq_ctx* c, void* hip_stream) {
+    if (!c) return FOURQ_ERR_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return FOURQ_OK;
+}
+FQ_API int fourq_ctx_sync(fourq_ctx* c) {
+    if (!c) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+FQ_API int fourq_ctx_lanes(const fourq_ctx* c, size_t* lanes) {
+    if (!c || !lanes) return FOURQ_ERR_INVALID;
+    *lanes = c->lanes;
+    return FOURQ_OK;
+}
+
+FQ_API int fourq_dev_alloc(fourq_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMalloc(out, bytes ? bytes : 16));
+    return FOURQ_OK;
+}
+FQ_API int fourq_dev_free(fourq_ctx* c, void* ptr) {
+    if (!c) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipFree(ptr));
+    return FOURQ_OK;
+}
+FQ_API int fourq_dev_upload(fourq_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+FQ_API int fourq_dev_download(fourq_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+
+FQ_API int fourq_table_windowed(fourq_ctx* c, const uint64_t* p, uint64_t* t) { return table_host(c, WINDOWED, p, t); }
+FQ_API int fourq_table_endo(fourq_ctx* c, const uint64_t* p, uint64_t* t) { return table_host(c, ENDO, p, t); }
+
+FQ_API int fourq_mul_endo_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) {
+    return p ? mul_host(c, ENDO, s, p, nullptr, o, n) : FOURQ_ERR_INVALID;
+}
+FQ_API int fourq_mul_windowed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) {
+    return p ? mul_host(c, WINDOWED, s, p, nullptr, o, n) : FOURQ_ERR_INVALID;
+}
+FQ_API int fourq_mul_endo_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) {
+    return p ? mul_dev(c, ENDO, s, p, nullptr, o, nullptr, n) : FOURQ_ERR_INVALID;
+}
+FQ_API int fourq_mul_windowed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) {
+    return p ? mul_dev(c, WINDOWED, s, p, nullptr, o, nullptr, n) : FOURQ_ERR_INVALID;
+}
+FQ_API int fourq_mul_endo_fixed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* t, uint64_t* o, size_t n) {
+    return t ? mul_host(c, ENDO, s, nullptr, t, o, n) : FOURQ_ERR_INVALID;
+}
+FQ_API int fourq_mul_windowed_fixed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* t, uint64_t* o, size_t n) {
+    return t ? mul_host(c, WINDOWED, s, nullptr, t, o, n) : FOURQ_ERR_INVALID;
+}
+FQ_API int fourq_mul_endo_fixed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* t, uint64_t* o, size_t n) {
+    return t ? mul_dev(c, ENDO, s, nullptr, t, o, nullptr, n) : FOURQ_ERR_INVALID;
+}
+FQ_API int fourq_mul_windowed_fixed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* t, uint64_t* o, size_t n) {
+    return t ? mul_dev(c, WINDOWED, s, nullptr, t, o, nullptr, n) : FOURQ_ERR_INVALID;
+}
+
+FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint8_t* flags,
+                                          const uint64_t* table, uint64_t* o, size_t n) {
+    if (!c || !s || !p || !flags || !table || !o || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    int rc = ensure_stage(c, 0);   // keep the staging buffer for the host wrapper; the index list has its own allocation
+    if (rc) return rc;
+    u32* idx = nullptr;
+    HIP_TRY(c, hipMalloc(&idx, n * sizeof(u32)));
+    u32 counts[2] = { 0, 0 };
+    rc = FOURQ_OK;
+    do {
+        if (hipMemsetAsync(c->part_counters, 0, 2 * sizeof(u32), c->stream) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, flags, (u32)n, idx, c->part_counters);
+        if (hipMemcpyAsync(counts, c->part_counters, sizeof counts, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        if (counts[0]) rc = mul_dev(c, ENDO, s, nullptr, table, o, idx, counts[0]);
+        if (!rc && counts[1]) rc = mul_dev(c, ENDO, s, p, nullptr, o, idx + (n - counts[1]), counts[1]);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = rc ? rc : FOURQ_ERR_HIP;
+    } while (0);
+    (void)hipFree(idx);
+    return rc;
+}
+FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint8_t* flags,
+                                      const uint64_t* table, uint64_t* o, size_t n) {
+    if (!c || !s || !p || !flags || !table || !o) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    size_t sb = n * 32, pb = n * 160, ob = n * 160, fb = (n + 15) / 16 * 16;
+    int rc = ensure_stage(c, sb + pb + ob + fb);
+    if (rc) return rc;
+    char* base = (char*)c->stage;
+    HIP_TRY(c, hipMemcpyAsync(base, s, sb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + sb, p, pb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(base + sb + pb + ob, flags, n, hipMemcpyHostToDevice, c->stream));
+    rc = fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)base, (const uint64_t*)(base + sb), (const uint8_t*)(base + sb + pb + ob),
+                                        table, (uint64_t*)(base + sb + pb), n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(o, base + sb + pb, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+
+FQ_API int fourq_dh_endo_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
+    return dh_host(c, ENDO, s, p, t, o, st, n);
+}
+FQ_API int fourq_dh_windowed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
+    return dh_host(c, WINDOWED, s, p, t, o, st, n);
+}
+FQ_API int fourq_dh_endo_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
+    return dh_dev(c, ENDO, s, p, t, o, st, n);
+}
+FQ_API int fourq_dh_windowed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
+    return dh_dev(c, WINDOWED, s, p, t, o, st, n);
+}
+
+FQ_API int fourq_prim_words(int op, size_t* in_words, size_t* out_words) {
+    const PrimShape* p = find_prim(op);
+    if (!p || !in_words || !out_words) return FOURQ_ERR_INVALID;
+    *in_words = p->in_words; *out_words = p->out_words;
+    return FOURQ_OK;
+}
+FQ_API int fourq_prim_batch(fourq_ctx* c, int op, const uint64_t* in, uint64_t* out, size_t n) {
+    const PrimShape* p = find_prim(op);
+    if (!c || !p || !in || !out || n > 0x7fffffffu) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    size_t ib = n * p->in_words * 8, ob = n * p->out_words * 8;
+    int rc = ensure_stage(c, ib + ob);
+    if (rc) return rc;
+    char* base = (char*)c->stage;
+    HIP_TRY(c, hipMemcpyAsync(base, in, ib, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(prim_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, op, (const u64*)base, (u64*)(base + ib),
+                       (u32)n, (u32)p->in_words, (u32)p->out_words);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, base + ib, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+
+}  // extern "C"

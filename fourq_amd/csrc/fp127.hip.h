@@ -1,0 +1,308 @@
+// GF(p) and GF(p^2) arithmetic for p = 2^127 - 1 on gfx950 (MI355X) VALU.
+//
+// Replaces, on the device, the reference's big-int field layer:
+//   GFp.add/sub/mul/sqr/neg/inv      bifurcation/fourq impl/fields.py:29-106
+//   GFp2.add/sub/mul/sqr/neg/conj/inv impl/fields.py:156-199
+//
+// Representation (chosen from tools/microbench/valu_rates.hip measurements on MI355X: carry-chain
+// and 3-operand instructions cost 2.4x a plain 32-bit add, v_mad_u64_u32 accumulating in place
+// costs the same as any other "slow" op): five 26-bit limbs in 32-bit registers, radix 2^26,
+// 130 bits, 2^130 == 8 (mod p).  Limbs are kept LAZILY: adds and subtractions are five plain
+// v_add_u32 / v_sub_u32 with no carry propagation; only multiplications normalise.  Every element
+// type carries a compile-time bound B meaning "each limb <= B * UNIT" (UNIT = 2^26 + 2^15), and
+// every multiplication static_asserts that its 64-bit column accumulators cannot overflow, so the
+// laziness is verified by the compiler, not by hope.
+//
+// A GF(p) product is 25 v_mad_u64_u32 accumulating into five 64-bit columns (the wrap-around
+// terms use the second operand pre-multiplied by 8); a GF(p^2) product accumulates its two GF(p)
+// products per component into the same columns (a0*b0 + (-a1)*b1 and a0*b1 + a1*b0), so it costs
+// 100 multiply-adds and only two normalisations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fq {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define FQ_DEV __device__ __forceinline__
+
+constexpr u32 LIMB_BITS = 26;
+constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1;
+constexpr u64 UNIT = (1ull << 26) + (1ull << 15);   // bound of a limb right after normalisation
+
+// limbs of K * (2^130 - 8) == 0 (mod p) in redundant form: used as the bias of subtractions
+FQ_DEV constexpr u32 bias_limb(int k, int i) { return (u32)k * (i == 0 ? (LIMB_MASK - 7) : LIMB_MASK); }
+
+template <int B> struct Fe {   // GF(p) element, every limb <= B * UNIT
+    u32 l[5];
+};
+template <int B> struct Fe2 {  // GF(p^2) element re + im*i
+    Fe<B> re, im;
+};
+
+// ---- bound widening (free) -----------------------------------------------------------------
+template <int B2, int B> FQ_DEV Fe<B2> widen(const Fe<B>& a) {
+    static_assert(B2 >= B, "cannot narrow a bound without a carry pass");
+    Fe<B2> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i];
+    return r;
+}
+template <int B2, int B> FQ_DEV Fe2<B2> widen(const Fe2<B>& a) {
+    Fe2<B2> r; r.re = widen<B2>(a.re); r.im = widen<B2>(a.im); return r;
+}
+
+// ---- add / sub / neg (lazy) ----------------------------------------------------------------
+template <int A, int B> FQ_DEV Fe<A + B> fe_add(const Fe<A>& a, const Fe<B>& b) {
+    static_assert((u64)(A + B) * UNIT < (1ull << 32), "limb overflow");
+    Fe<A + B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// a - b computed as a + ((B+1)*(2^130-8) - b): limbwise non-negative because
+// (B+1)*(2^26-8) >= B*UNIT for every B used here (checked below).
+template <int A, int B> FQ_DEV Fe<A + B + 1> fe_sub(const Fe<A>& a, const Fe<B>& b) {
+    static_assert((u64)(A + B + 1) * UNIT < (1ull << 32), "limb overflow");
+    static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");
+    Fe<A + B + 1> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] + (bias_limb(B + 1, i) - b.l[i]);
+    return r;
+}
+template <int B> FQ_DEV Fe<B + 1> fe_neg(const Fe<B>& b) {
+    static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");
+    Fe<B + 1> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = bias_limb(B + 1, i) - b.l[i];
+    return r;
+}
+template <int B> FQ_DEV Fe<2 * B> fe_dbl(const Fe<B>& a) { return fe_add(a, a); }
+
+// ---- normalisation of five 64-bit columns ----------------------------------------------------
+// Input: value = sum c[k] * 2^(26k), each c[k] + incoming carry < 2^64.
+// Output: limbs 0,2,3,4 < 2^26 and limb 1 < 2^26 + 2^15  (i.e. bound 1).
+FQ_DEV Fe<1> fe_normalize(u64 c0, u64 c1, u64 c2, u64 c3, u64 c4) {
+    Fe<1> r;
+    c1 += c0 >> LIMB_BITS;
+    c2 += c1 >> LIMB_BITS;
+    c3 += c2 >> LIMB_BITS;
+    c4 += c3 >> LIMB_BITS;
+    u64 w = ((c4 >> LIMB_BITS) << 3) + ((u32)c0 & LIMB_MASK);   // 2^130 == 8 ; w < 2^42
+    r.l[0] = (u32)w & LIMB_MASK;
+    r.l[1] = ((u32)c1 & LIMB_MASK) + (u32)(w >> LIMB_BITS);
+    r.l[2] = (u32)c2 & LIMB_MASK;
+    r.l[3] = (u32)c3 & LIMB_MASK;
+    r.l[4] = (u32)c4 & LIMB_MASK;
+    return r;
+}
+
+// 32-bit carry pass: any bound -> bound 1 (15 cheap VALU ops).
+template <int B> FQ_DEV Fe<1> fe_carry(const Fe<B>& a) {
+    static_assert((u64)B * UNIT + (1ull << 20) < (1ull << 32), "limb overflow");
+    Fe<1> r;
+    u32 t1 = a.l[1] + (a.l[0] >> LIMB_BITS);
+    u32 t2 = a.l[2] + (t1 >> LIMB_BITS);
+    u32 t3 = a.l[3] + (t2 >> LIMB_BITS);
+    u32 t4 = a.l[4] + (t3 >> LIMB_BITS);
+    u32 t0 = (a.l[0] & LIMB_MASK) + ((t4 >> LIMB_BITS) << 3);   // < 2^26 + 2^9
+    r.l[0] = t0 & LIMB_MASK;
+    r.l[1] = (t1 & LIMB_MASK) + (t0 >> LIMB_BITS);
+    r.l[2] = t2 & LIMB_MASK;
+    r.l[3] = t3 & LIMB_MASK;
+    r.l[4] = t4 & LIMB_MASK;
+    return r;
+}
+template <int B> FQ_DEV Fe2<1> fe2_carry(const Fe2<B>& a) {
+    Fe2<1> r; r.re = fe_carry(a.re); r.im = fe_carry(a.im); return r;
+}
+
+// ---- column multiply-accumulate ----------------------------------------------------------------
+// c[k] += sum_{i+j == k (mod 5)} a_i * (i+j < 5 ? b_j : 8*b_j) ; b8 = 8*b limbwise.
+struct Cols {
+    u64 c[5];
+};
+FQ_DEV void cols_zero(Cols& s) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) s.c[k] = 0;
+}
+FQ_DEV void cols_mac(Cols& s, const u32 a[5], const u32 b[5], const u32 b8[5]) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            int j = k - i;
+            u32 bj = (j >= 0) ? b[j] : b8[j + 5];
+            s.c[k] += (u64)a[i] * bj;   // v_mad_u64_u32, accumulating in place
+        }
+    }
+}
+template <int B> FQ_DEV void times8(u32 out[5], const Fe<B>& b) {
+    static_assert((u64)8 * B * UNIT < (1ull << 32), "8*b does not fit 32 bits");
+#pragma unroll
+    for (int i = 0; i < 5; i++) out[i] = b.l[i] << 3;
+}
+// column bound: n products, each <= (A*UNIT) * (8*B*UNIT); plus normalisation carries (< 2^40)
+constexpr bool cols_ok(u64 weighted) {   // weighted = sum over accumulated products of A*B
+    return weighted * 5 * 8 <= ((~0ull - (1ull << 41)) / (UNIT * UNIT));
+}
+
+// ---- GF(p) multiplication ----------------------------------------------------------------------
+template <int A, int B> FQ_DEV Fe<1> fe_mul(const Fe<A>& a, const Fe<B>& b) {   // fields.py:42-45
+    static_assert(cols_ok((u64)A * B), "column overflow");
+    u32 b8[5];
+    times8(b8, b);
+    Cols s; cols_zero(s);
+    cols_mac(s, a.l, b.l, b8);
+    return fe_normalize(s.c[0], s.c[1], s.c[2], s.c[3], s.c[4]);
+}
+template <int A> FQ_DEV Fe<1> fe_sqr(const Fe<A>& a) {                          // fields.py:48-51
+    static_assert(cols_ok((u64)A * A), "column overflow");
+    static_assert((u64)16 * A * UNIT < (1ull << 32), "16*a does not fit 32 bits");
+    // 15 products: squares once, cross terms through a doubled operand
+    const u32 *x = a.l;
+    u32 d[5], e[5];   // d = 2a, e = 8a (wrap-around), f = 16a (wrap-around and doubled)
+#pragma unroll
+    for (int i = 0; i < 5; i++) { d[i] = x[i] << 1; e[i] = x[i] << 3; }
+    u64 c0 = (u64)x[0] * x[0] + (u64)d[1] * (e[4]) + (u64)d[2] * e[3];
+    u64 c1 = (u64)d[0] * x[1] + (u64)d[2] * e[4] + (u64)x[3] * e[3];
+    u64 c2 = (u64)d[0] * x[2] + (u64)x[1] * x[1] + (u64)d[3] * e[4];
+    u64 c3 = (u64)d[0] * x[3] + (u64)d[1] * x[2] + (u64)x[4] * e[4];
+    u64 c4 = (u64)d[0] * x[4] + (u64)d[1] * x[3] + (u64)x[2] * x[2];
+    return fe_normalize(c0, c1, c2, c3, c4);
+}
+
+// ---- GF(p^2) -----------------------------------------------------------------------------------
+template <int A, int B> FQ_DEV Fe2<A + B> fe2_add(const Fe2<A>& a, const Fe2<B>& b) {   // fields.py:157-159
+    Fe2<A + B> r; r.re = fe_add(a.re, b.re); r.im = fe_add(a.im, b.im); return r;
+}
+template <int A, int B> FQ_DEV Fe2<A + B + 1> fe2_sub(const Fe2<A>& a, const Fe2<B>& b) {   // fields.py:162-164
+    Fe2<A + B + 1> r; r.re = fe_sub(a.re, b.re); r.im = fe_sub(a.im, b.im); return r;
+}
+template <int B> FQ_DEV Fe2<B + 1> fe2_neg(const Fe2<B>& a) {                              // fields.py:184-186
+    Fe2<B + 1> r; r.re = fe_neg(a.re); r.im = fe_neg(a.im); return r;
+}
+template <int B> FQ_DEV Fe2<B + 1> fe2_conj(const Fe2<B>& a) {                             // fields.py:189-191
+    Fe2<B + 1> r; r.re = widen<B + 1>(a.re); r.im = fe_neg(a.im); return r;
+}
+template <int B> FQ_DEV Fe2<2 * B> fe2_dbl(const Fe2<B>& a) { return fe2_add(a, a); }
+
+// (a0 + a1 i)(b0 + b1 i) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) i                  fields.py:167-173
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) {
+    static_assert(cols_ok((u64)(2 * A + 1) * B), "column overflow");
+    u32 b0x8[5], b1x8[5];
+    times8(b0x8, b.re);
+    times8(b1x8, b.im);
+    Fe<A + 1> na1 = fe_neg(a.im);
+    Fe2<1> r;
+    {
+        Cols s; cols_zero(s);
+        cols_mac(s, a.re.l, b.re.l, b0x8);
+        cols_mac(s, na1.l, b.im.l, b1x8);
+        r.re = fe_normalize(s.c[0], s.c[1], s.c[2], s.c[3], s.c[4]);
+    }
+    {
+        Cols s; cols_zero(s);
+        cols_mac(s, a.re.l, b.im.l, b1x8);
+        cols_mac(s, a.im.l, b.re.l, b0x8);
+        r.im = fe_normalize(s.c[0], s.c[1], s.c[2], s.c[3], s.c[4]);
+    }
+    return r;
+}
+// (a0 + a1 i)^2 = (a0 + a1)(a0 - a1) + (2 a0 a1) i                               fields.py:176-181
+template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
+    Fe<2 * A> s = fe_add(a.re, a.im);
+    Fe<2 * A + 1> d = fe_sub(a.re, a.im);
+    Fe<2 * A> t = fe_dbl(a.re);
+    Fe2<1> r;
+    r.re = fe_mul(d, s);
+    r.im = fe_mul(t, a.im);
+    return r;
+}
+
+// ---- canonical form, packing --------------------------------------------------------------------
+// 128-bit little-endian container (what the C ABI carries) <-> limbs.
+FQ_DEV Fe<1> fe_unpack(u64 lo, u64 hi) {   // any 128-bit value; the residue class is what counts
+    Fe<1> r;
+    r.l[0] = (u32)lo & LIMB_MASK;
+    r.l[1] = (u32)(lo >> 26) & LIMB_MASK;
+    r.l[2] = (u32)((lo >> 52) | (hi << 12)) & LIMB_MASK;
+    r.l[3] = (u32)(hi >> 14) & LIMB_MASK;
+    r.l[4] = (u32)(hi >> 40);              // 24 bits
+    return r;
+}
+// Fully reduced representative in [0, p): what the reference's `% p1271` returns.
+template <int B> FQ_DEV void fe_canon(const Fe<B>& a, u64& lo, u64& hi) {
+    Fe<1> t = fe_carry(a);                 // limbs tight, value < 2^130 + 2^41
+    // fold bits >= 127 (limb 4 holds bits 104..129): 2^127 == 1
+    u32 l0 = t.l[0] + (t.l[4] >> 23), l1 = t.l[1], l2 = t.l[2], l3 = t.l[3], l4 = t.l[4] & 0x7fffff;
+    l1 += l0 >> 26; l0 &= LIMB_MASK;
+    l2 += l1 >> 26; l1 &= LIMB_MASK;
+    l3 += l2 >> 26; l2 &= LIMB_MASK;
+    l4 += l3 >> 26; l3 &= LIMB_MASK;       // value < 2^127 + 2^5
+    l0 += l4 >> 23; l4 &= 0x7fffff;        // second fold: now value <= 2^127 - 1 + small, limbs may ripple once
+    l1 += l0 >> 26; l0 &= LIMB_MASK;
+    l2 += l1 >> 26; l1 &= LIMB_MASK;
+    l3 += l2 >> 26; l2 &= LIMB_MASK;
+    l4 += l3 >> 26; l3 &= LIMB_MASK;       // value in [0, 2^127)
+    // p itself is the non-canonical zero
+    bool is_p = (l0 & l1 & l2 & l3) == LIMB_MASK && l4 == 0x7fffff;
+    u32 keep = is_p ? 0u : ~0u;
+    l0 &= keep; l1 &= keep; l2 &= keep; l3 &= keep; l4 &= keep;
+    lo = (u64)l0 | ((u64)l1 << 26) | ((u64)l2 << 52);
+    hi = ((u64)l2 >> 12) | ((u64)l3 << 14) | ((u64)l4 << 40);
+}
+template <int B> FQ_DEV bool fe_is_zero(const Fe<B>& a) {
+    u64 lo, hi; fe_canon(a, lo, hi); return (lo | hi) == 0;
+}
+template <int A, int B> FQ_DEV bool fe_equal(const Fe<A>& a, const Fe<B>& b) {
+    u64 alo, ahi, blo, bhi; fe_canon(a, alo, ahi); fe_canon(b, blo, bhi);
+    return alo == blo && ahi == bhi;
+}
+template <int A, int B> FQ_DEV bool fe2_equal(const Fe2<A>& a, const Fe2<B>& b) {
+    return fe_equal(a.re, b.re) & fe_equal(a.im, b.im);
+}
+
+// x if mask == ~0 else y (mask must be 0 or ~0): the branch-free GFp.select of fields.py:59-64
+template <int B> FQ_DEV Fe<B> fe_select(u32 mask, const Fe<B>& x, const Fe<B>& y) {
+    Fe<B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = y.l[i] ^ (mask & (x.l[i] ^ y.l[i]));
+    return r;
+}
+template <int B> FQ_DEV Fe2<B> fe2_select(u32 mask, const Fe2<B>& x, const Fe2<B>& y) {   // fields.py:236-238
+    Fe2<B> r; r.re = fe_select(mask, x.re, y.re); r.im = fe_select(mask, x.im, y.im); return r;
+}
+
+// ---- inversion: x^(2^127-3) by the reference's fixed chain (fields.py:66-106) -----------------
+FQ_DEV Fe<1> fe_sqr_n(Fe<1> x, int n) {
+#pragma unroll 1
+    for (int i = 0; i < n; i++) x = fe_sqr(x);
+    return x;
+}
+__device__ __noinline__ Fe<1> fe_inv(Fe<1> x) {
+    Fe<1> x2 = fe_mul(x, fe_sqr(x));             // 2^2 - 1
+    Fe<1> x4 = fe_mul(x2, fe_sqr_n(x2, 2));      // 2^4 - 1
+    Fe<1> x8 = fe_mul(x4, fe_sqr_n(x4, 4));      // 2^8 - 1
+    Fe<1> x16 = fe_mul(x8, fe_sqr_n(x8, 8));     // 2^16 - 1
+    Fe<1> x32 = fe_mul(x16, fe_sqr_n(x16, 16));  // 2^32 - 1
+    Fe<1> t = fe_mul(fe_sqr_n(x32, 32), x32);    // 2^64 - 1
+    t = fe_mul(fe_sqr_n(t, 32), x32);            // 2^96 - 1
+    t = fe_mul(fe_sqr_n(t, 16), x16);            // 2^112 - 1
+    t = fe_mul(fe_sqr_n(t, 8), x8);              // 2^120 - 1
+    t = fe_mul(fe_sqr_n(t, 4), x4);              // 2^124 - 1
+    t = fe_mul(fe_sqr(t), x);                    // 2^125 - 1
+    return fe_mul(fe_sqr_n(t, 2), x);            // 2^127 - 3
+}
+// conj(a) / (a0^2 + a1^2)                                                       fields.py:193-199
+template <int B> FQ_DEV Fe2<1> fe2_inv(const Fe2<B>& a) {
+    Fe<1> n = fe_inv(fe_carry(fe_add(fe_sqr(a.re), fe_sqr(a.im))));
+    Fe2<1> r;
+    r.re = fe_mul(n, a.re);
+    r.im = fe_mul(n, fe_neg(a.im));
+    return r;
+}
+
+}  // namespace fq

@@ -1,0 +1,161 @@
+// Scalar recoding on the device: the integer side of MUL_windowed / MUL_endo.
+//
+//   fixed-window digits   curve4q.py:216-226   (m mod N, forced odd, 63 signed odd base-16 digits)
+//   decompose(m)          curve4q.py:339-356   (4-dimensional GLV-style decomposition, mod 2^64)
+//   recode(v)             curve4q.py:358-380   (65 sign bits + 65 three-bit digits)
+//
+// One lane owns one scalar; everything is straight-line 64-bit integer code.
+#pragma once
+#include "fp127.hip.h"
+
+namespace fq {
+
+typedef unsigned __int128 u128;
+
+// ((a * m) >> 256) mod 2^64 for 256-bit a, m: column 4 of the product with exact carries from
+// columns 0..3 (t_i of curve4q.py:344-347; only its low 64 bits matter).
+FQ_DEV u64 mul_shift256(const u64 a[4], const u64 m[4]) {
+    u64 w0, w1, w2, w3, w4;
+    u128 t;
+    // row 0
+    t = (u128)a[0] * m[0];                       w0 = (u64)t;
+    t = (u128)a[0] * m[1] + (u64)(t >> 64);      w1 = (u64)t;
+    t = (u128)a[0] * m[2] + (u64)(t >> 64);      w2 = (u64)t;
+    t = (u128)a[0] * m[3] + (u64)(t >> 64);      w3 = (u64)t; w4 = (u64)(t >> 64);
+    // row 1
+    t = (u128)a[1] * m[0] + w1;                  w1 = (u64)t;
+    t = (u128)a[1] * m[1] + w2 + (u64)(t >> 64); w2 = (u64)t;
+    t = (u128)a[1] * m[2] + w3 + (u64)(t >> 64); w3 = (u64)t;
+    w4 += a[1] * m[3] + (u64)(t >> 64);
+    // row 2
+    t = (u128)a[2] * m[0] + w2;                  w2 = (u64)t;
+    t = (u128)a[2] * m[1] + w3 + (u64)(t >> 64); w3 = (u64)t;
+    w4 += a[2] * m[2] + (u64)(t >> 64);
+    // row 3
+    t = (u128)a[3] * m[0] + w3;                  w3 = (u64)t;
+    w4 += a[3] * m[1] + (u64)(t >> 64);
+    (void)w0; (void)w1; (void)w2; (void)w3;
+    return w4;
+}
+
+FQ_DEV void decompose(const u64 m[4], u64 v[4]) {                        // curve4q.py:339-356
+    u64 t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 ell[4] = { ELL[i][0], ELL[i][1], ELL[i][2], ELL[i][3] };
+        t[i] = mul_shift256(ell, m);
+    }
+    u64 ac[4], acp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 a = (i == 0) ? m[0] : 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) a -= t[j] * BASIS[j][i];
+        ac[i] = a + OFFSET_C[i];
+        acp[i] = a + OFFSET_CP[i];
+    }
+    u64 mask = (u64)0 - (ac[0] & 1);            // select(ac[0] odd, ac, acp), 64-bit mask as :340-342
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = acp[i] ^ (mask & (ac[i] ^ acp[i]));
+}
+
+// recode(): sign bit of step i is bit i of `sign` (i < 64; step 64 is always positive), digit of
+// step i is bit i of the planes d[0..2]; `top` is digit 64.
+struct EndoDigits {
+    u64 sign;
+    u64 d[3];
+    u32 top;
+};
+FQ_DEV EndoDigits recode(const u64 vin[4]) {                             // curve4q.py:358-380
+    EndoDigits r;
+    r.sign = vin[0] >> 1;                       // bit(v1, i+1); bit 64 of a 64-bit value is 0
+    u64 v1 = vin[1], v2 = vin[2], v3 = vin[3];
+    u64 p1 = 0, p2 = 0, p3 = 0;
+    u64 s = r.sign;
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) {
+        u64 nb1 = ~(s >> i) & 1;                // c = (b1 | bj) ^ b1 = ~b1 & bj
+        u64 b;
+        b = v1 & 1; p1 |= b << i; v1 = (v1 >> 1) + (nb1 & b);
+        b = v2 & 1; p2 |= b << i; v2 = (v2 >> 1) + (nb1 & b);
+        b = v3 & 1; p3 |= b << i; v3 = (v3 >> 1) + (nb1 & b);
+    }
+    r.d[0] = p1; r.d[1] = p2; r.d[2] = p3;
+    r.top = (u32)(v1 + 2 * v2 + 4 * v3);
+    return r;
+}
+FQ_DEV u32 endo_digit(const EndoDigits& e, int i) {   // i in 0..63 (wave-uniform)
+    return (u32)((e.d[0] >> i) & 1) | ((u32)((e.d[1] >> i) & 1) << 1) | ((u32)((e.d[2] >> i) & 1) << 2);
+}
+FQ_DEV u32 endo_neg_mask(const EndoDigits& e, int i) { // ~0 when the step subtracts (sign bit 0)
+    return (u32)((e.sign >> i) & 1) - 1u;
+}
+
+// ---- fixed window ---------------------------------------------------------------------------------
+// r = m mod N, made odd by adding N (curve4q.py:217-219).  Digit i is then
+//   d_i = ((r >> 4i) & 31 | 1) - 16     (the loop at :220-222 keeps r odd, so r_{i+1} = (r_i >> 4) | 1)
+// and d_62 = (r >> 252) | 1 (:223).  Digits are therefore random-access: no sequential pass.
+struct WinScalar {
+    u64 r[4];
+};
+FQ_DEV bool ge256(const u64 a[4], const u64 b[4]) {
+    bool ge = true;   // compare from the least significant word up: the last difference wins
+#pragma unroll
+    for (int i = 0; i < 4; i++) ge = (a[i] == b[i]) ? ge : (a[i] > b[i]);
+    return ge;
+}
+FQ_DEV WinScalar win_reduce(const u64 m[4]) {
+    u64 r[4] = { m[0], m[1], m[2], m[3] };
+#pragma unroll 1
+    for (int k = 10; k >= 0; k--) {             // N < 2^246: restoring division by N << k
+        u64 s[4];
+        s[0] = ORDER_N[0] << k;
+#pragma unroll
+        for (int i = 1; i < 4; i++) s[i] = (ORDER_N[i] << k) | (k ? (ORDER_N[i - 1] >> (64 - k)) : 0);
+        u64 keep = ge256(r, s) ? ~(u64)0 : 0;
+        u64 borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            u64 si = s[i] & keep;
+            u64 d1 = r[i] - si;
+            u64 b1 = r[i] < si;
+            u64 d2 = d1 - borrow;
+            u64 b2 = d1 < borrow;
+            r[i] = d2; borrow = b1 | b2;
+        }
+    }
+    u64 addn = (r[0] & 1) ? 0 : ~(u64)0;        // even -> r += N
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 ni = ORDER_N[i] & addn;
+        u64 s1 = r[i] + ni;
+        u64 c1 = s1 < ni;
+        u64 s2 = s1 + carry;
+        u64 c2 = s2 < carry;
+        r[i] = s2; carry = c1 | c2;
+    }
+    WinScalar w; w.r[0] = r[0]; w.r[1] = r[1]; w.r[2] = r[2]; w.r[3] = r[3];
+    return w;
+}
+// (sgn << 3) | ind for digit i in 0..61 from the 5-bit window at bit 4i
+FQ_DEV u32 win_code_from_window(u32 w5) {
+    u32 w = (w5 & 31) | 1;
+    u32 pos = w >> 4;                           // d > 0  <=>  window > 16
+    u32 ind = ((pos ? w : ~w) & 15) >> 1;       // (|d| - 1) / 2
+    return (pos << 3) | ind;
+}
+FQ_DEV u32 win_window(const WinScalar& w, int i) {   // bits [4i, 4i+4] of r, i wave-uniform
+    int bit = 4 * i, word = bit >> 6, off = bit & 63;
+    u64 lo = (word == 0) ? w.r[0] : (word == 1) ? w.r[1] : (word == 2) ? w.r[2] : w.r[3];
+    u64 hi = (word == 0) ? w.r[1] : (word == 1) ? w.r[2] : (word == 2) ? w.r[3] : 0;
+    u64 v = lo >> off;
+    if (off > 59) v |= hi << (64 - off);
+    return (u32)v & 31;
+}
+FQ_DEV u32 win_top_code(const WinScalar& w) {        // digit 62 = (r >> 252) | 1, always positive
+    u32 d = (u32)(w.r[3] >> 60) | 1;
+    return (1u << 3) | (((d - 1) >> 1) & 7);
+}
+
+}  // namespace fq

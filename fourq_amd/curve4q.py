@@ -1,0 +1,237 @@
+"""Drop-in mirror of the reference's `impl/curve4q.py` API, computed on the MI355X.
+
+Same names, argument meaning, value conventions (nested tuples of Python ints) and error
+behaviour as bifurcation/fourq; every function runs on the GPU through libfourq_amd.so -- there
+is no CPU arithmetic here beyond packing tuples into words.  Single calls are batches of one;
+use `fourq_amd.Engine` (or the `*_batch` helpers below) for throughput.
+
+    reference symbol (curve4q.py)                 here
+    MUL_windowed :188 / MUL_endo :405             same, plus aliases mul_windowed / mul
+    table_windowed :179 / table_endo :385         same
+    DH_core :446, DH_windowed :464, DH_endo :467  same; dh_exchange = DH_endo(a, DH_endo(b, G))
+    PointOnCurve :23, AffineToR1 :100, R1toAffine :103, R1toR2 :109, R1toR3 :119, R2toR4 :129,
+    DBL :138, ADD_core :155, ADD :174, tau :258, tau_dual :269, upsilon :282, chi :304,
+    phi :318, psi :321, decompose :339, recode :358
+"""
+import numpy as np
+
+from . import codec
+from .constants import N, Gx, Gy, Ox, Oy, d, P127  # noqa: F401  (re-exported, as the reference does)
+from .engine import default_engine
+from .fields import GFp, GFp2  # noqa: F401
+
+p1271 = P127
+
+_MSG = {1: "Point not on curve", 2: "DH computation resulted in neutral point"}   # curve4q.py:448, :460
+
+
+def _prim_pt(op, *points):
+    row = np.concatenate([codec.pack_point(P) for P in points]).reshape(1, -1)
+    return codec.unpack_fp2s(default_engine().prim(op, row)[0])
+
+
+# ---- membership and representations ------------------------------------------------------------
+def PointOnCurve(P):
+    (X, Y) = P
+    return bool(default_engine().prim("PT_ON_CURVE", codec.pack_point((X, Y)).reshape(1, -1))[0, 0])
+
+
+def AffineToR1(X, Y):
+    return (X, Y, GFp2.one, X, Y)
+
+
+def R1toAffine(P):
+    (X, Y, Z, Ta, Tb) = P
+    return _prim_pt("PT_R1TOAFFINE", P)
+
+
+def R1toR2(P):
+    (X, Y, Z, Ta, Tb) = P
+    return _prim_pt("PT_R1TOR2", P)
+
+
+def R1toR3(P):
+    (X, Y, Z, Ta, Tb) = P
+    return _prim_pt("PT_R1TOR3", P)
+
+
+def R2toR4(P):
+    (N_, D_, E_, F_) = P
+    return _prim_pt("PT_R2TOR4", P)
+
+
+def DBL(P):
+    (X1, Y1, Z1) = P[:3]
+    return _prim_pt("PT_DBL", (X1, Y1, Z1, GFp2.zero, GFp2.zero))
+
+
+def ADD_core(P, Q):
+    (N1, D1, E1, F1) = P
+    (N2, D2, Z2, T2) = Q
+    return _prim_pt("PT_ADD_CORE", P, Q)
+
+
+def ADD(P, Q):
+    (X, Y, Z, Ta, Tb) = P
+    (N2, D2, Z2, T2) = Q
+    return _prim_pt("PT_ADD", P, Q)
+
+
+# ---- endomorphisms -----------------------------------------------------------------------------
+def tau(P):
+    (X1, Y1, Z1) = P
+    return _prim_pt("PT_TAU", P)
+
+
+def tau_dual(P):
+    (X1, Y1, Z1) = P
+    return _prim_pt("PT_TAU_DUAL", P)
+
+
+def upsilon(P):
+    (X1, Y1, Z1) = P
+    return _prim_pt("PT_UPSILON", P)
+
+
+def chi(P):
+    (X1, Y1, Z1) = P
+    return _prim_pt("PT_CHI", P)
+
+
+def phi(P):
+    return _prim_pt("PT_PHI", tuple(P[:3]) + (GFp2.zero, GFp2.zero))
+
+
+def psi(P):
+    return _prim_pt("PT_PSI", tuple(P[:3]) + (GFp2.zero, GFp2.zero))
+
+
+# ---- recoding ----------------------------------------------------------------------------------
+def decompose(m):
+    out = default_engine().prim("SC_DECOMPOSE", codec.pack_scalars([m]))[0]
+    return [int(x) for x in out]
+
+
+def recode(v):
+    """(m, d): 65 sign bits and 65 digits of the decomposed scalar v (curve4q.py:358-380)."""
+    (v1, v2, v3, v4) = v
+    row = np.array([[v1, v2, v3, v4]], dtype=np.uint64)
+    sign, d0, d1, d2, top = (int(x) for x in default_engine().prim("SC_RECODE", row)[0])
+    signs = [(sign >> i) & 1 for i in range(64)] + [1]
+    digits = [((d0 >> i) & 1) | (((d1 >> i) & 1) << 1) | (((d2 >> i) & 1) << 2) for i in range(64)] + [top]
+    return (signs, digits)
+
+
+def windowed_digits(m):
+    """(sgn[0..62], ind[0..62]) of MUL_windowed (curve4q.py:216-226)."""
+    raw = default_engine().prim("SC_WINDOWED", codec.pack_scalars([_reduce_windowed(m)]))[0].tobytes()
+    return [b >> 3 for b in raw[:63]], [b & 7 for b in raw[:63]]
+
+
+# ---- tables and scalar multiplication ----------------------------------------------------------
+def table_windowed(P):
+    (X, Y, Z, Ta, Tb) = P
+    return codec.unpack_table(default_engine().table_windowed(codec.pack_point(P)))
+
+
+def table_endo(P):
+    (X, Y, Z, Ta, Tb) = P
+    return codec.unpack_table(default_engine().table_endo(codec.pack_point(P)))
+
+
+def _reduce_windowed(m):
+    # MUL_windowed starts with `reduced = m % N` (curve4q.py:217), so any integer is acceptable
+    return m if 0 <= m < (1 << 256) else m % N
+
+
+def _check_endo_scalar(m):
+    if not 0 <= m < (1 << 256):
+        raise ValueError("MUL_endo takes a scalar in [0, 2^256) (it is used unreduced, curve4q.py:433)")
+    return m
+
+
+def MUL_windowed(m, P, table=None):
+    (X, Y, Z, Ta, Tb) = P                                  # shape check, curve4q.py:190
+    s = codec.pack_scalars([_reduce_windowed(m)])
+    eng = default_engine()
+    if table:                                              # `if not T` in the reference, curve4q.py:211
+        out = eng.mul_windowed_fixed(s, codec.pack_table(table))
+    else:
+        out = eng.mul_windowed(s, codec.pack_point(P).reshape(1, 20))
+    return codec.unpack_fp2s(out[0])
+
+
+def MUL_endo(m, P, table=None):
+    (X, Y, Z, Ta, Tb) = P                                  # shape check, curve4q.py:407
+    s = codec.pack_scalars([_check_endo_scalar(m)])
+    eng = default_engine()
+    if table:
+        out = eng.mul_endo_fixed(s, codec.pack_table(table))
+    else:
+        out = eng.mul_endo(s, codec.pack_point(P).reshape(1, 20))
+    return codec.unpack_fp2s(out[0])
+
+
+def MUL_windowed_batch(ms, Ps=None, table=None):
+    """[MUL_windowed(m_i, P_i)] (table=None) or [MUL_windowed(m_i, ., table)] in one launch."""
+    s = codec.pack_scalars([_reduce_windowed(m) for m in ms])
+    eng = default_engine()
+    out = eng.mul_windowed_fixed(s, codec.pack_table(table)) if table else eng.mul_windowed(s, codec.pack_points(Ps, 5))
+    return codec.unpack_points(out)
+
+
+def MUL_endo_batch(ms, Ps=None, table=None):
+    s = codec.pack_scalars([_check_endo_scalar(m) for m in ms])
+    eng = default_engine()
+    out = eng.mul_endo_fixed(s, codec.pack_table(table)) if table else eng.mul_endo(s, codec.pack_points(Ps, 5))
+    return codec.unpack_points(out)
+
+
+# ---- Diffie-Hellman ----------------------------------------------------------------------------
+def _dh(kind, m, P, table):
+    (X, Y) = P
+    eng = default_engine()
+    s = codec.pack_scalars([_reduce_windowed(m) if kind == "windowed" else _check_endo_scalar(m)])
+    pts = codec.pack_point((X, Y)).reshape(1, 8)
+    t = codec.pack_table(table) if table else None
+    out, status = (eng.dh_windowed if kind == "windowed" else eng.dh_endo)(s, pts, t)
+    if status[0]:
+        raise Exception(_MSG[int(status[0])])
+    return codec.unpack_fp2s(out[0])
+
+
+def DH_core(m, P, mul, table=None):
+    if mul is MUL_windowed:
+        return _dh("windowed", m, P, table)
+    if mul is MUL_endo:
+        return _dh("endo", m, P, table)
+    raise ValueError("DH_core: mul must be MUL_windowed or MUL_endo")
+
+
+def DH_windowed(m, P, table=None):
+    return _dh("windowed", m, P, table)
+
+
+def DH_endo(m, P, table=None):
+    return _dh("endo", m, P, table)
+
+
+def DH_batch(kind, ms, Ps, table=None):
+    """Batched DH_<kind>: returns (list of affine points or None, list of exception messages or None)."""
+    eng = default_engine()
+    red = _reduce_windowed if kind == "windowed" else _check_endo_scalar
+    s = codec.pack_scalars([red(m) for m in ms])
+    t = codec.pack_table(table) if table else None
+    out, status = (eng.dh_windowed if kind == "windowed" else eng.dh_endo)(s, codec.pack_points(Ps, 2), t)
+    pts = codec.unpack_points(out)
+    return [p if st == 0 else None for p, st in zip(pts, status)], [_MSG.get(int(st)) for st in status]
+
+
+# BASELINE.json spellings
+mul = MUL_endo
+mul_windowed = MUL_windowed
+
+
+def dh_exchange(a, b, table=None):
+    """DH_endo(a, DH_endo(b, G)); `table` = table_endo([392]G) accelerates the fixed-base half."""
+    return DH_endo(a, DH_endo(b, (Gx, Gy), table=table))

@@ -1,0 +1,210 @@
+"""Batched FourQ engine: a thin object over one fourq_ctx (one GPU, one HIP stream).
+
+Array conventions are the C ABI's (include/fourq_amd.h): uint64 little-endian words,
+scalars (n,4), affine points (n,8), R1 points (n,20), tables (128,).  Host entry points take and
+return numpy arrays; the `*_dev` entry points take device pointers (ints, or anything with a
+`data_ptr()` such as a torch tensor), enqueue on the engine's stream and do not synchronise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import PRIM, FourQError, check
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return ctypes.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        return ctypes.c_void_p(x.data_ptr())
+    raise TypeError("expected a pointer, numpy array or tensor, got %r" % type(x))
+
+
+def _host(a, cols, dtype=np.uint64):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+class Engine:
+    def __init__(self, device=None, stream=None):
+        self._lib = _lib.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        ctx = ctypes.c_void_p()
+        check(self._lib.fourq_ctx_create(int(device), ctypes.byref(ctx)))
+        self._ctx = ctx
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ---- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.fourq_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        check(rc, self._ctx)
+
+    def set_stream(self, stream):
+        """`stream`: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        handle = getattr(stream, "cuda_stream", stream)
+        self._ck(self._lib.fourq_ctx_set_stream(self._ctx, ctypes.c_void_p(handle) if handle else None))
+
+    def sync(self):
+        self._ck(self._lib.fourq_ctx_sync(self._ctx))
+
+    @property
+    def lanes(self):
+        n = ctypes.c_size_t()
+        self._ck(self._lib.fourq_ctx_lanes(self._ctx, ctypes.byref(n)))
+        return n.value
+
+    # ---- tables ----------------------------------------------------------------------------
+    def _table(self, fn, p_r1):
+        p = _host(p_r1, None).ravel()
+        if p.size != 20:
+            raise ValueError("an R1 point is 20 words")
+        out = np.empty(128, dtype=np.uint64)
+        self._ck(fn(self._ctx, _ptr(p), _ptr(out)))
+        return out
+
+    def table_endo(self, p_r1):
+        return self._table(self._lib.fourq_table_endo, p_r1)
+
+    def table_windowed(self, p_r1):
+        return self._table(self._lib.fourq_table_windowed, p_r1)
+
+    # ---- scalar multiplication (host arrays) -----------------------------------------------
+    def _mul(self, fn, scalars, second, second_cols):
+        s = _host(scalars, 4)
+        b = _host(second, second_cols)
+        if second_cols == 20 and len(b) != len(s):
+            raise ValueError("scalars and points differ in length")
+        if second_cols is None and b.size != 128:
+            raise ValueError("a table is 128 words")
+        out = np.empty((len(s), 20), dtype=np.uint64)
+        self._ck(fn(self._ctx, _ptr(s), _ptr(b), _ptr(out), len(s)))
+        return out
+
+    def mul_endo(self, scalars, points_r1):
+        return self._mul(self._lib.fourq_mul_endo_batch, scalars, points_r1, 20)
+
+    def mul_windowed(self, scalars, points_r1):
+        return self._mul(self._lib.fourq_mul_windowed_batch, scalars, points_r1, 20)
+
+    def mul_endo_fixed(self, scalars, table):
+        return self._mul(self._lib.fourq_mul_endo_fixed_batch, scalars, table, None)
+
+    def mul_windowed_fixed(self, scalars, table):
+        return self._mul(self._lib.fourq_mul_windowed_fixed_batch, scalars, table, None)
+
+    def mul_endo_mixed(self, scalars, points_r1, flags, table):
+        s, p = _host(scalars, 4), _host(points_r1, 20)
+        f = _host(flags, None, np.uint8).ravel()
+        t = _host(table, None).ravel()
+        if not (len(s) == len(p) == len(f)) or t.size != 128:
+            raise ValueError("mixed batch: inconsistent shapes")
+        out = np.empty((len(s), 20), dtype=np.uint64)
+        self._ck(self._lib.fourq_mul_endo_mixed_batch(self._ctx, _ptr(s), _ptr(p), _ptr(f), _ptr(t), _ptr(out), len(s)))
+        return out
+
+    # ---- Diffie-Hellman ----------------------------------------------------------------------
+    def _dh(self, fn, scalars, points_affine, table):
+        s, p = _host(scalars, 4), _host(points_affine, 8)
+        if len(s) != len(p):
+            raise ValueError("scalars and points differ in length")
+        t = None if table is None else _host(table, None).ravel()
+        if t is not None and t.size != 128:
+            raise ValueError("a table is 128 words")
+        out = np.empty((len(s), 8), dtype=np.uint64)
+        status = np.empty(len(s), dtype=np.uint8)
+        self._ck(fn(self._ctx, _ptr(s), _ptr(p), _ptr(t), _ptr(out), _ptr(status), len(s)))
+        return out, status
+
+    def dh_endo(self, scalars, points_affine, table=None):
+        return self._dh(self._lib.fourq_dh_endo_batch, scalars, points_affine, table)
+
+    def dh_windowed(self, scalars, points_affine, table=None):
+        return self._dh(self._lib.fourq_dh_windowed_batch, scalars, points_affine, table)
+
+    def dh_exchange(self, a_scalars, b_scalars, base_affine, table392=None):
+        """One exchange per row: DH_endo(a_i, DH_endo(b_i, base)) (curve4q.py:731).
+
+        `table392` = table_endo([392]base) makes the first half fixed-base.  Returns (affine, status):
+        status is the first failure of either half."""
+        b = _host(b_scalars, 4)
+        base = np.broadcast_to(_host(base_affine, None).reshape(1, 8), (len(b), 8))
+        mid, st1 = self.dh_endo(b, base, table392)
+        out, st2 = self.dh_endo(a_scalars, mid)
+        status = np.where(st1 != 0, st1, st2).astype(np.uint8)
+        out[status != 0] = 0
+        return out, status
+
+    # ---- device-pointer flavour (async on the engine's stream) ---------------------------------
+    def mul_endo_dev(self, scalars, points_r1, out_r1, n):
+        self._ck(self._lib.fourq_mul_endo_batch_dev(self._ctx, _ptr(scalars), _ptr(points_r1), _ptr(out_r1), n))
+
+    def mul_windowed_dev(self, scalars, points_r1, out_r1, n):
+        self._ck(self._lib.fourq_mul_windowed_batch_dev(self._ctx, _ptr(scalars), _ptr(points_r1), _ptr(out_r1), n))
+
+    def mul_endo_fixed_dev(self, scalars, table_host, out_r1, n):
+        t = _host(table_host, None).ravel()
+        self._ck(self._lib.fourq_mul_endo_fixed_batch_dev(self._ctx, _ptr(scalars), _ptr(t), _ptr(out_r1), n))
+
+    def mul_windowed_fixed_dev(self, scalars, table_host, out_r1, n):
+        t = _host(table_host, None).ravel()
+        self._ck(self._lib.fourq_mul_windowed_fixed_batch_dev(self._ctx, _ptr(scalars), _ptr(t), _ptr(out_r1), n))
+
+    def mul_endo_mixed_dev(self, scalars, points_r1, flags, table_host, out_r1, n):
+        t = _host(table_host, None).ravel()
+        self._ck(self._lib.fourq_mul_endo_mixed_batch_dev(self._ctx, _ptr(scalars), _ptr(points_r1), _ptr(flags), _ptr(t), _ptr(out_r1), n))
+
+    def dh_endo_dev(self, scalars, points_affine, table_host, out_affine, status, n):
+        t = None if table_host is None else _host(table_host, None).ravel()
+        self._ck(self._lib.fourq_dh_endo_batch_dev(self._ctx, _ptr(scalars), _ptr(points_affine), _ptr(t), _ptr(out_affine), _ptr(status), n))
+
+    def dh_windowed_dev(self, scalars, points_affine, table_host, out_affine, status, n):
+        t = None if table_host is None else _host(table_host, None).ravel()
+        self._ck(self._lib.fourq_dh_windowed_batch_dev(self._ctx, _ptr(scalars), _ptr(points_affine), _ptr(t), _ptr(out_affine), _ptr(status), n))
+
+    # ---- primitives ----------------------------------------------------------------------------
+    def prim(self, op, inputs):
+        """Run primitive `op` (name in _lib.PRIM or its int) over rows of `inputs`; returns (n, out_words)."""
+        code = PRIM[op] if isinstance(op, str) else int(op)
+        iw, ow = ctypes.c_size_t(), ctypes.c_size_t()
+        self._ck(self._lib.fourq_prim_words(code, ctypes.byref(iw), ctypes.byref(ow)))
+        x = _host(inputs, iw.value)
+        out = np.zeros((len(x), ow.value), dtype=np.uint64)
+        self._ck(self._lib.fourq_prim_batch(self._ctx, code, _ptr(x), _ptr(out), len(x)))
+        return out
+
+
+_default = None
+
+
+def default_engine():
+    """Process-wide engine on device LOCAL_RANK (or 0).  Raises FourQError when no MI355X is usable."""
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default
+
+
+__all__ = ["Engine", "default_engine", "FourQError"]

@@ -1,0 +1,90 @@
+"""Mirror of the reference's field namespaces `GFp` / `GFp2` (impl/fields.py:9-238), computed by
+the device field layer (fp127.hip.h) through the primitive ABI.  Static methods, tuples of ints in
+and out, results canonical in [0, p) exactly as `% p1271` returns them."""
+import numpy as np
+
+from . import codec
+from .constants import P127
+from .engine import default_engine
+
+p1271 = P127
+
+
+def _fp(op, x, y=0):
+    row = np.array([[*codec._fp_words(x), *codec._fp_words(y)]], dtype=np.uint64)
+    out = default_engine().prim(op, row)[0]
+    return int(out[0]) | (int(out[1]) << 64)
+
+
+def _fp2(op, a, b=(0, 0)):
+    row = codec.pack_fp2s([a, b]).reshape(1, 8)
+    return codec.unpack_fp2s(default_engine().prim(op, row)[0])[0]
+
+
+class GFp:
+    half = 1 << 126                                    # fields.py:16
+
+    @staticmethod
+    def add(x, y):                                     # fields.py:30
+        return _fp("FP_ADD", x, y)
+
+    @staticmethod
+    def sub(x, y):                                     # fields.py:36
+        return _fp("FP_SUB", x, y)
+
+    @staticmethod
+    def mul(x, y):                                     # fields.py:42
+        return _fp("FP_MUL", x, y)
+
+    @staticmethod
+    def sqr(x):                                        # fields.py:48
+        return _fp("FP_SQR", x)
+
+    @staticmethod
+    def neg(x):                                        # fields.py:54
+        return _fp("FP_NEG", x)
+
+    @staticmethod
+    def inv(x):                                        # fields.py:67
+        return _fp("FP_INV", x)
+
+    @staticmethod
+    def select(c, x, y):                               # fields.py:60 -- host-side: no arithmetic involved
+        return x if c == 1 else y
+
+
+class GFp2:
+    zero, one, two = (0, 0), (1, 0), (2, 0)            # fields.py:140-142
+    half = (GFp.half, 0)
+
+    @staticmethod
+    def add(a, b):                                     # fields.py:157
+        return _fp2("FP2_ADD", a, b)
+
+    @staticmethod
+    def sub(a, b):                                     # fields.py:162
+        return _fp2("FP2_SUB", a, b)
+
+    @staticmethod
+    def mul(a, b):                                     # fields.py:167
+        return _fp2("FP2_MUL", a, b)
+
+    @staticmethod
+    def sqr(a):                                        # fields.py:176
+        return _fp2("FP2_SQR", a)
+
+    @staticmethod
+    def neg(a):                                        # fields.py:184
+        return _fp2("FP2_NEG", a)
+
+    @staticmethod
+    def conj(a):                                       # fields.py:189
+        return _fp2("FP2_CONJ", a)
+
+    @staticmethod
+    def inv(a):                                        # fields.py:194
+        return _fp2("FP2_INV", a)
+
+    @staticmethod
+    def select(c, x, y):                               # fields.py:237
+        return x if c == 1 else y

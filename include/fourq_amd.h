@@ -1,0 +1,156 @@
+/* fourq_amd -- batched FourQ (Curve4Q) scalar multiplication on AMD MI355X (gfx950).
+ *
+ * C ABI of libfourq_amd.so.  This is the drop-in boundary for the hot path of the reference
+ * implementation bifurcation/fourq (pure Python; citations are impl/<file>:<line>).  The
+ * reference has no FFI of its own -- its boundary is the Python signatures
+ *     MUL_windowed(m, P, table=None)   curve4q.py:188      table_windowed(P)   curve4q.py:179
+ *     MUL_endo(m, P, table=None)       curve4q.py:405      table_endo(P)       curve4q.py:385
+ *     DH_windowed / DH_endo            curve4q.py:464-468  (DH_core curve4q.py:446)
+ * so each entry point below is the batched form of one of those, and the ctypes stub that
+ * presents the reference signatures on top of it is fourq_amd/curve4q.py.
+ *
+ * Data layout (all little-endian 64-bit words; plain pointers, caller-allocated):
+ *   GF(p) element      2 words, value in [0, 2^128) accepted, canonical [0, p) returned
+ *   GF(p^2) element    4 words  (re, im)                         fields.py:134
+ *   scalar             4 words  (256-bit, as the reference's KAT generator curve4q.py:552-559)
+ *   affine point       8 words  (x, y)
+ *   R1 point          20 words  (X, Y, Z, Ta, Tb)                curve4q.py:100-106
+ *   R2 point          16 words  (X+Y, Y-X, 2Z, 2dT)              curve4q.py:109-116
+ *   table            128 words  8 R2 points                      curve4q.py:179-185, :385-403
+ *
+ * Every function returns FOURQ_OK (0) or a negative error code and never throws.  A context is
+ * bound to one device and one HIP stream; calls on one context must not overlap, different
+ * contexts are independent.  There is no CPU fallback: without a usable gfx950 device
+ * fourq_ctx_create fails.
+ *
+ * Pointer flavours: functions ending in _dev take DEVICE pointers, enqueue on the context's
+ * stream and return without synchronising (use fourq_ctx_sync or the caller's stream).  The same
+ * names without _dev take HOST pointers and are synchronous (H2D copy, kernel, D2H copy).
+ */
+#ifndef FOURQ_AMD_H
+#define FOURQ_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOURQ_OK 0
+#define FOURQ_ERR_INVALID (-1)   /* NULL pointer, bad size or bad enum */
+#define FOURQ_ERR_NODEVICE (-2)  /* no HIP device / device is not gfx950-compatible */
+#define FOURQ_ERR_NOMEM (-3)     /* device or host allocation failed */
+#define FOURQ_ERR_HIP (-4)       /* a HIP runtime call or kernel launch failed (see fourq_last_error) */
+
+/* per-element status of the DH entry points; the Python wrapper re-raises 1 and 2 with the
+ * reference's exact messages (curve4q.py:448, :460) */
+#define FOURQ_DH_OK 0
+#define FOURQ_DH_NOT_ON_CURVE 1
+#define FOURQ_DH_NEUTRAL 2
+
+#define FOURQ_SCALAR_WORDS 4
+#define FOURQ_AFFINE_WORDS 8
+#define FOURQ_R1_WORDS 20
+#define FOURQ_R2_WORDS 16
+#define FOURQ_TABLE_WORDS 128
+
+typedef struct fourq_ctx fourq_ctx;
+
+/* ---- library / context ---------------------------------------------------------------------- */
+int fourq_version(void);                       /* 10000*major + 100*minor + patch */
+const char *fourq_strerror(int code);
+const char *fourq_last_error(const fourq_ctx *ctx);   /* detail of the last FOURQ_ERR_HIP */
+
+int fourq_ctx_create(int device, fourq_ctx **out);
+int fourq_ctx_destroy(fourq_ctx *ctx);
+/* Use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the
+ * context's own stream.  The context never synchronises an external stream behind the caller's back. */
+int fourq_ctx_set_stream(fourq_ctx *ctx, void *hip_stream);
+int fourq_ctx_sync(fourq_ctx *ctx);
+/* Resident lanes the ladder kernels are launched with (scratch is sized for this many). */
+int fourq_ctx_lanes(const fourq_ctx *ctx, size_t *lanes);
+
+/* Plain device-memory helpers so that a host program without a HIP binding can use the _dev API. */
+int fourq_dev_alloc(fourq_ctx *ctx, size_t bytes, void **out);
+int fourq_dev_free(fourq_ctx *ctx, void *ptr);
+int fourq_dev_upload(fourq_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int fourq_dev_download(fourq_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- look-up tables: table_windowed(P) curve4q.py:179, table_endo(P) curve4q.py:385 ----------- */
+int fourq_table_windowed(fourq_ctx *ctx, const uint64_t *p_r1, uint64_t *table);
+int fourq_table_endo(fourq_ctx *ctx, const uint64_t *p_r1, uint64_t *table);
+
+/* ---- variable-base scalar multiplication: MUL_*(m_i, P_i), table=None ------------------------- */
+/* out_r1[i] = raw R1 tuple the reference returns (curve4q.py:235, :442), n x 20 words */
+int fourq_mul_endo_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, uint64_t *out_r1, size_t n);
+int fourq_mul_windowed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, uint64_t *out_r1, size_t n);
+int fourq_mul_endo_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, uint64_t *out_r1, size_t n);
+int fourq_mul_windowed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, uint64_t *out_r1, size_t n);
+
+/* ---- fixed-base scalar multiplication: MUL_*(m_i, P, table=T) --------------------------------- */
+/* `table` is 128 words (host pointer in both flavours: it is 1 KiB and is staged once per call) */
+int fourq_mul_endo_fixed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *table, uint64_t *out_r1, size_t n);
+int fourq_mul_windowed_fixed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *table, uint64_t *out_r1, size_t n);
+int fourq_mul_endo_fixed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *table, uint64_t *out_r1, size_t n);
+int fourq_mul_windowed_fixed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *table, uint64_t *out_r1, size_t n);
+
+/* ---- mixed batch (BASELINE.json config 5): element i is fixed-base (flags[i] == 0, uses `table`)
+ *      or variable-base (flags[i] != 0, uses points_r1[i]); MUL_endo in both cases ---------------- */
+int fourq_mul_endo_mixed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, const uint8_t *flags,
+                               const uint64_t *table, uint64_t *out_r1, size_t n);
+int fourq_mul_endo_mixed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, const uint8_t *flags,
+                                   const uint64_t *table, uint64_t *out_r1, size_t n);
+
+/* ---- Diffie-Hellman: DH_core(m_i, P_i, mul, table) curve4q.py:446-462 --------------------------
+ * table == NULL: variable base (the table is built from [392]P_i); otherwise `table` (host pointer)
+ * is used for every element exactly as the reference does (it ignores the point, curve4q.py:209, :426).
+ * status[i]: FOURQ_DH_*; out_affine[i] is all zero when status[i] != 0. */
+int fourq_dh_endo_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,
+                        uint64_t *out_affine, uint8_t *status, size_t n);
+int fourq_dh_windowed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,
+                            uint64_t *out_affine, uint8_t *status, size_t n);
+int fourq_dh_endo_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,
+                            uint64_t *out_affine, uint8_t *status, size_t n);
+int fourq_dh_windowed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,
+                                uint64_t *out_affine, uint8_t *status, size_t n);
+
+/* ---- primitives (one reference function per op, batched) --------------------------------------
+ * Used by the Python mirror of the reference's helper API (GFp.*, GFp2.*, DBL, ADD, phi, ...) and by
+ * the parity tests to check every layer of the path on the GPU.  in/out are HOST pointers;
+ * element strides are fourq_prim_words(). */
+enum fourq_prim {
+    /* GFp, fields.py:29-106: in = a[2] b[2] */
+    FOURQ_FP_ADD = 0, FOURQ_FP_SUB = 1, FOURQ_FP_MUL = 2, FOURQ_FP_SQR = 3, FOURQ_FP_NEG = 4, FOURQ_FP_INV = 5,
+    /* GFp2, fields.py:156-199: in = a[4] b[4] */
+    FOURQ_FP2_ADD = 16, FOURQ_FP2_SUB = 17, FOURQ_FP2_MUL = 18, FOURQ_FP2_SQR = 19, FOURQ_FP2_NEG = 20,
+    FOURQ_FP2_CONJ = 21, FOURQ_FP2_INV = 22,
+    /* curve4q.py:100-175 */
+    FOURQ_PT_DBL = 32,          /* R1[20] -> R1[20] */
+    FOURQ_PT_ADD = 33,          /* R1[20] R2[16] -> R1[20] */
+    FOURQ_PT_ADD_CORE = 34,     /* R3[16] R2[16] -> R1[20] */
+    FOURQ_PT_R1TOR2 = 35,       /* R1[20] -> R2[16] */
+    FOURQ_PT_R1TOR3 = 36,       /* R1[20] -> R3[16] */
+    FOURQ_PT_R2TOR4 = 37,       /* R2[16] -> R4[12] */
+    /* curve4q.py:258-322 */
+    FOURQ_PT_TAU = 38,          /* (X,Y,Z)[12] -> [12] */
+    FOURQ_PT_TAU_DUAL = 39,     /* [12] -> R1[20] */
+    FOURQ_PT_UPSILON = 40,      /* [12] -> [12] */
+    FOURQ_PT_CHI = 41,          /* [12] -> [12] */
+    FOURQ_PT_PHI = 42,          /* R1[20] -> R1[20] */
+    FOURQ_PT_PSI = 43,          /* R1[20] -> R1[20] */
+    FOURQ_PT_ON_CURVE = 44,     /* affine[8] -> [1] (0/1)            curve4q.py:23 */
+    FOURQ_PT_COFACTOR392 = 45,  /* affine[8] -> R1[20]               curve4q.py:450-455 */
+    FOURQ_PT_R1TOAFFINE = 46,   /* R1[20] -> affine[8]               curve4q.py:103 */
+    /* curve4q.py:216-226, :339-380 */
+    FOURQ_SC_DECOMPOSE = 64,    /* m[4] -> a1..a4 [4] */
+    FOURQ_SC_RECODE = 65,       /* v[4] = decompose(m) -> [5]: sign bits 0..63, digit bit-planes 0,1,2, digit 64 */
+    FOURQ_SC_WINDOWED = 66      /* m[4] -> [8]: 63 bytes, byte i = (sgn[i] << 3) | ind[i] */
+};
+int fourq_prim_words(int op, size_t *in_words, size_t *out_words);
+int fourq_prim_batch(fourq_ctx *ctx, int op, const uint64_t *in, uint64_t *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOURQ_AMD_H */

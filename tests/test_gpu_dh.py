@@ -1,0 +1,116 @@
+"""GPU parity of the Diffie-Hellman wrapper (DH_core, curve4q.py:446-468) through the C ABI and
+through the reference-shaped Python API, including the two rejection cases and their messages."""
+import random
+
+import numpy as np
+import pytest
+
+import curve4q_oracle as o
+import oracle_c as oc
+from conftest import unhex
+from fourq_amd import codec
+
+pytestmark = pytest.mark.gpu
+
+G = (o.Gx, o.Gy)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fourq_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def seeded_scalars(seed, n):
+    rng = random.Random(seed)
+    return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+
+
+def test_dh_golden(eng, golden):
+    raw = golden("dh.json", raw=True)
+    rows = unhex(raw["dh"])
+    s = codec.pack_scalars([r[0] for r in rows])
+    p = codec.pack_points([r[1] for r in rows], 2)
+    out, st = eng.dh_endo(s, p)
+    assert not st.any() and codec.unpack_points(out) == [r[2] for r in rows]
+    out, st = eng.dh_windowed(s, p)
+    assert not st.any() and codec.unpack_points(out) == [r[3] for r in rows]
+    fx = unhex(raw["fixed"])
+    s = codec.pack_scalars([r[0] for r in fx["rows"]])
+    p = codec.pack_points([G] * len(fx["rows"]), 2)
+    out, st = eng.dh_endo(s, p, codec.pack_table(fx["table_endo"]))
+    assert not st.any() and codec.unpack_points(out) == [r[1] for r in fx["rows"]]
+    out, st = eng.dh_windowed(s, p, codec.pack_table(fx["table_windowed"]))
+    assert not st.any() and codec.unpack_points(out) == [r[2] for r in fx["rows"]]
+    for a, b, ab in unhex(raw["exchange"]):
+        out, st = eng.dh_exchange(codec.pack_scalars([a]), codec.pack_scalars([b]), codec.pack_point(G))
+        assert st[0] == 0 and codec.unpack_fp2s(out[0]) == ab
+
+
+def test_reference_api_and_errors(golden):
+    """The drop-in module: same calls, same exceptions and messages as curve4q.py:446-468, :765-778."""
+    from fourq_amd import curve4q as c
+    raw = golden("dh.json", raw=True)
+    for m, Pt, e, w in unhex(raw["dh"])[:4]:
+        assert c.DH_endo(m, Pt) == e and c.DH_windowed(m, Pt) == w
+        assert c.DH_core(m, Pt, c.MUL_endo) == e
+    for m, Pt, msg in raw["reject"]:
+        for dh in (c.DH_endo, c.DH_windowed):
+            with pytest.raises(Exception) as ei:
+                dh(int(m, 16), unhex(Pt))
+            assert str(ei.value) == msg
+    with pytest.raises(ValueError):
+        c.MUL_endo(1, ((0, 0), (1, 0)))            # malformed R1 tuple -> unpacking error, as curve4q.py:407
+    G1 = c.AffineToR1(c.Gx, c.Gy)
+    assert c.R1toAffine(c.MUL_endo(1, G1)) == G and c.R1toAffine(c.mul(2, G1)) == o.R1toAffine(o.DBL(G1))
+    T = c.table_endo(G1)
+    assert T == o.table_endo(G1) and c.MUL_endo(12345, G1, table=T) == o.MUL_endo(12345, G1)
+    assert c.MUL_windowed(-7, G1) == o.MUL_windowed(-7, G1)      # any integer: reduced mod N first (curve4q.py:217)
+    assert c.PointOnCurve(G) and not c.PointOnCurve(((0, 0), (0, 0)))
+    assert c.decompose(0x1234) == o.decompose(0x1234)
+    assert tuple(map(list, c.recode(c.decompose(987654321)))) == tuple(map(list, o.recode(o.decompose(987654321))))
+    assert c.GFp2.mul((2, 3), (5, 7)) == (o.P127 - 11, 29) and c.GFp.mul(c.GFp.inv(13), 13) == 1
+    assert c.DBL(G1) == o.DBL(G1) and c.phi(G1) == o.phi(G1) and c.psi(G1) == o.psi(G1)
+    a, b = 0xA5A5 << 200, 0x5A5A << 190
+    assert c.dh_exchange(a, b) == o.dh_exchange(a, b)
+
+
+def test_dh_batch_with_failures_vs_c_oracle(eng, golden):
+    """4096 elements, some off-curve, some of small order: per-element status and zeroed outputs."""
+    n = 4096
+    s = seeded_scalars(40002, n)
+    mid, st = eng.dh_endo(seeded_scalars(40003, n), np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0))
+    assert not st.any()
+    pts = mid.copy()
+    p392 = codec.pack_point(unhex(golden("kat.json", raw=True)["P392"]))
+    pts[5::97] = p392                              # 392-torsion -> neutral
+    pts[11::101, 0] ^= np.uint64(1)                # perturbed x -> not on curve
+    pts[17] = 0                                    # ((0,0),(0,0)) -> not on curve
+    want, wst = oc.dh(oc.ENDO, s, pts)
+    got, gst = eng.dh_endo(s, pts)
+    assert np.array_equal(gst, wst) and np.array_equal(got, want)
+    assert set(np.unique(gst)) == {0, 1, 2}
+    want, wst = oc.dh(oc.WINDOWED, s[:1024], pts[:1024])
+    got, gst = eng.dh_windowed(s[:1024], pts[:1024])
+    assert np.array_equal(gst, wst) and np.array_equal(got, want)
+
+
+def test_dh_symmetry_and_392_property(eng):
+    """curve4q.py:709-741 at batch scale: DH(a, DH(b, G)) == DH(b, DH(a, G)); DH(m, P) == [392 m]P."""
+    n = 8192
+    a, b = seeded_scalars(61, n), seeded_scalars(62, n)
+    g = codec.pack_point(G)
+    ab, s1 = eng.dh_exchange(a, b, g)
+    ba, s2 = eng.dh_exchange(b, a, g)
+    assert not s1.any() and not s2.any() and np.array_equal(ab, ba)
+    t392 = eng.table_endo(codec.pack_point(o.MUL_endo(392, o.AffineToR1(*G))))
+    ab_fixed, s3 = eng.dh_exchange(a, b, g, table392=t392)        # fixed-base first half (curve4q.py:743-762)
+    assert not s3.any() and np.array_equal(ab_fixed, ab)
+    k = 512
+    m392 = codec.pack_scalars([(392 * x) % o.N for x in codec.unpack_scalars(a[:k])])
+    g1 = np.repeat(codec.pack_point(o.AffineToR1(*G)).reshape(1, 20), k, axis=0)
+    direct = eng.prim("PT_R1TOAFFINE", eng.mul_windowed(m392, g1))
+    dh, st = eng.dh_endo(a[:k], np.repeat(g.reshape(1, 8), k, axis=0))
+    assert not st.any() and np.array_equal(dh, direct)

@@ -1,0 +1,166 @@
+"""GPU parity of the scalar-multiplication hot path (MUL_endo / MUL_windowed, variable and fixed
+base) through the C ABI: golden vectors, the reference's KAT chain, full-batch comparison against
+the C oracle, ragged/empty batches, and size-independent properties at BASELINE.json sizes."""
+import random
+
+import numpy as np
+import pytest
+
+import curve4q_oracle as o
+import oracle_c as oc
+from fourq_amd import codec
+
+pytestmark = pytest.mark.gpu
+
+G1 = o.AffineToR1(o.Gx, o.Gy)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fourq_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def seeded_scalars(seed, n):
+    rng = random.Random(seed)
+    return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+
+
+def torsion_points(eng, seed, n):
+    """n projective N-torsion points: raw R1 outputs of fixed-base [k_i]G."""
+    tbl = oc.table(oc.ENDO, codec.pack_point(G1))
+    return eng.mul_endo_fixed(seeded_scalars(seed, n), tbl)
+
+
+def test_tables(eng, golden):
+    for Pt, tw, te in golden("tables.json")["tables"]:
+        assert codec.unpack_table(eng.table_windowed(codec.pack_point(Pt))) == list(tw)
+        assert codec.unpack_table(eng.table_endo(codec.pack_point(Pt))) == list(te)
+
+
+def test_mul_golden(eng, golden):
+    g = golden("mul.json")
+    rows = g["var"] + g["edge"]
+    s = codec.pack_scalars([r[0] for r in rows])
+    p = codec.pack_points([r[1] for r in rows], 5)
+    assert codec.unpack_points(eng.mul_endo(s, p)) == [r[2] for r in rows]
+    assert codec.unpack_points(eng.mul_windowed(s, p)) == [r[3] for r in rows]
+    for blk in g["fixed"]:
+        s = codec.pack_scalars([r[0] for r in blk["rows"]])
+        assert codec.unpack_points(eng.mul_endo_fixed(s, codec.pack_table(blk["table_endo"]))) == [r[1] for r in blk["rows"]]
+        assert codec.unpack_points(eng.mul_windowed_fixed(s, codec.pack_table(blk["table_windowed"]))) == [r[2] for r in blk["rows"]]
+
+
+@pytest.mark.parametrize("kind", ["endo", "windowed"])
+def test_mul_chain_kat(eng, golden, kind):
+    """curve4q.py:549-567: 1000 chained scalar mults, outputs fed back as projective inputs."""
+    from conftest import unhex
+    fn = eng.mul_endo if kind == "endo" else eng.mul_windowed
+    A = codec.pack_point(G1).reshape(1, 20)
+    for m in o.kat_scalars(1000):
+        A = fn(codec.pack_scalars([m]), A)
+    assert o.R1toAffine(codec.unpack_fp2s(A[0])) == unhex(golden("kat.json", raw=True)["mulP"])
+
+
+def test_mul_one_two_and_fixed_equals_variable(eng):   # curve4q.py:571-598, :677-704
+    g = codec.pack_point(G1).reshape(1, 20)
+    dbl = o.R1toAffine(o.DBL(G1))
+    rng = random.Random(5)
+    ms = [rng.getrandbits(256) for _ in range(10)]
+    for var, fixed, tab in ((eng.mul_endo, eng.mul_endo_fixed, eng.table_endo), (eng.mul_windowed, eng.mul_windowed_fixed, eng.table_windowed)):
+        T = tab(g)
+        for m, want in ((1, (o.Gx, o.Gy)), (2, dbl)):
+            s = codec.pack_scalars([m])
+            assert o.R1toAffine(codec.unpack_fp2s(var(s, g)[0])) == want
+            assert o.R1toAffine(codec.unpack_fp2s(fixed(s, T)[0])) == want
+        s = codec.pack_scalars(ms)
+        assert np.array_equal(fixed(s, T), var(s, np.repeat(g, len(ms), axis=0)))   # full R1 tuples, as :593, :699
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 257, 1000])
+def test_ragged_batches(eng, n):
+    s = seeded_scalars(77 + n, n)
+    pts = torsion_points(eng, 1234 + n, n) if n else np.empty((0, 20), dtype=np.uint64)
+    assert np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts) if n else np.empty((0, 20), dtype=np.uint64))
+    assert np.array_equal(eng.mul_windowed(s, pts), oc.mul(oc.WINDOWED, s, pts) if n else np.empty((0, 20), dtype=np.uint64))
+    tbl = oc.table(oc.ENDO, codec.pack_point(G1))
+    assert np.array_equal(eng.mul_endo_fixed(s, tbl), oc.mul(oc.ENDO, s, None, tbl) if n else np.empty((0, 20), dtype=np.uint64))
+
+
+def test_full_batch_cfg2_vs_c_oracle(eng):
+    """BASELINE.json config 2: 2^16 variable-base MUL_endo, random 256-bit scalars (seeds of SURVEY 8d);
+    every one of the 65536 raw R1 outputs compared with the C oracle, plus a Python-oracle sample."""
+    n = 1 << 16
+    s = seeded_scalars(20002, n)
+    pts = torsion_points(eng, 20003, n)
+    got = eng.mul_endo(s, pts)
+    assert np.array_equal(got, oc.mul(oc.ENDO, s, pts))
+    for i in range(0, n, n // 16):
+        m = codec.unpack_scalars(s[i:i + 1])[0]
+        assert codec.unpack_fp2s(got[i]) == o.MUL_endo(m, codec.unpack_fp2s(pts[i]))
+    gotw = eng.mul_windowed(s[:8192], pts[:8192])
+    assert np.array_equal(gotw, oc.mul(oc.WINDOWED, s[:8192], pts[:8192]))
+
+
+def test_full_batch_cfg3_fixed_base(eng):
+    """BASELINE.json config 3: 2^20 fixed-base MUL_windowed(m, G, table): a 2^15 slice against the C oracle,
+    and on the whole batch the size-independent property MUL_windowed == MUL_endo as affine points
+    (two independent algorithms), checked on the GPU by cross-multiplication X1*Z2 == X2*Z1, Y1*Z2 == Y2*Z1."""
+    n = 1 << 20
+    s = seeded_scalars(30002, n)
+    g = codec.pack_point(G1)
+    tw, te = eng.table_windowed(g), eng.table_endo(g)
+    w = eng.mul_windowed_fixed(s, tw)
+    e = eng.mul_endo_fixed(s, te)
+    k = 1 << 15
+    assert np.array_equal(w[:k], oc.mul(oc.WINDOWED, s[:k], None, tw))
+    assert np.array_equal(e[:k], oc.mul(oc.ENDO, s[:k], None, te))
+    x1z2 = eng.prim("FP2_MUL", np.concatenate([w[:, 0:4], e[:, 8:12]], axis=1))
+    x2z1 = eng.prim("FP2_MUL", np.concatenate([e[:, 0:4], w[:, 8:12]], axis=1))
+    y1z2 = eng.prim("FP2_MUL", np.concatenate([w[:, 4:8], e[:, 8:12]], axis=1))
+    y2z1 = eng.prim("FP2_MUL", np.concatenate([e[:, 4:8], w[:, 8:12]], axis=1))
+    assert np.array_equal(x1z2, x2z1) and np.array_equal(y1z2, y2z1)
+
+
+def test_linearity_property(eng):
+    """[a]P + [b]P == [a+b]P (mod N) on 4096 random points: affine equality via the DH-free path."""
+    n = 4096
+    a, b = seeded_scalars(1, n), seeded_scalars(2, n)
+    ai, bi = codec.unpack_scalars(a), codec.unpack_scalars(b)
+    c = codec.pack_scalars([(x + y) % o.N for x, y in zip(ai, bi)])
+    pts = torsion_points(eng, 3, n)
+    pa, pb, pc = eng.mul_endo(a, pts), eng.mul_endo(b, pts), eng.mul_endo(c, pts)
+    sm = eng.prim("PT_ADD", np.concatenate([pa, eng.prim("PT_R1TOR2", pb)], axis=1))
+    assert np.array_equal(eng.prim("PT_R1TOAFFINE", sm), eng.prim("PT_R1TOAFFINE", pc))
+
+
+def test_mixed_batch(eng):
+    """BASELINE.json config 5 shape: element i fixed-base (flag 0) or variable-base (flag 1)."""
+    n = 5000
+    s = seeded_scalars(50001, n)
+    pts = torsion_points(eng, 50003, n)
+    flags = (np.frombuffer(random.Random(50002).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
+    tbl = eng.table_endo(codec.pack_point(G1))
+    got = eng.mul_endo_mixed(s, pts, flags, tbl)
+    want = np.where(flags[:, None] == 0, oc.mul(oc.ENDO, s, None, tbl), oc.mul(oc.ENDO, s, pts))
+    assert np.array_equal(got, want)
+    assert np.array_equal(eng.mul_endo_mixed(s, pts, np.zeros(n, np.uint8), tbl), oc.mul(oc.ENDO, s, None, tbl))
+    assert np.array_equal(eng.mul_endo_mixed(s, pts, np.ones(n, np.uint8), tbl), oc.mul(oc.ENDO, s, pts))
+
+
+def test_device_pointer_api_matches_host_api(eng):
+    import torch
+    n = 3000
+    s, pts = seeded_scalars(9, n), torsion_points(eng, 10, n)
+    ds = torch.from_numpy(s.view(np.int64)).cuda()
+    dp = torch.from_numpy(pts.view(np.int64)).cuda()
+    out = torch.empty((n, 20), dtype=torch.int64, device="cuda")
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        eng.mul_endo_dev(ds, dp, out, n)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_stream(None)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), eng.mul_endo(s, pts))
