@@ -1,0 +1,69 @@
+"""The N>1 path on CPU: two processes over gloo shard a batch contiguously, each computes its
+shard, and rank 0 gathers.  On the GPU box the same code runs with backend "nccl" (RCCL) and the
+HIP engine; here the per-shard compute is the C oracle so that the test needs no GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from fourq_amd.dist import gather_rows, shard_bounds, sharded_map
+
+
+def test_shard_bounds_cover_without_overlap():
+    for n in (0, 1, 7, 64, 65, 1 << 16, (1 << 22) + 3):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _worker(rank, world, port, n, result_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c as oc
+    from bench import seeded_scalars
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scalars = seeded_scalars(7, n)
+        table = oc.table(oc.ENDO, _g1())
+        local = sharded_map(lambda s: oc.mul(oc.ENDO, s, None, table), [scalars], n)
+        lo, hi = shard_bounds(n, rank, world)
+        assert local.shape == (hi - lo, 20)
+        full = gather_rows(torch.from_numpy(local.view(np.int64)), n, dst=0)
+        if rank == 0:
+            np.save(result_path, full.numpy().view(np.uint64))
+        else:
+            assert full is None
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _g1():
+    from fourq_amd import codec, constants
+    return codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
+
+
+@pytest.mark.parametrize("n", [257, 1000])
+def test_two_rank_shard_and_gather_gloo(tmp_path, n):
+    import oracle_c as oc
+    from bench import seeded_scalars
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(2, port, n, out), nprocs=2, join=True)
+    want = oc.mul(oc.ENDO, seeded_scalars(7, n), None, oc.table(oc.ENDO, _g1()))
+    assert np.array_equal(np.load(out), want)
