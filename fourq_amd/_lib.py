@@ -5,7 +5,7 @@ import os
 from ctypes import POINTER, c_char_p, c_int, c_size_t, c_uint8, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
+LIB_PATH = os.environ.get("FOURQ_AMD_LIB") or os.path.join(HERE, "libfourq_amd.so")   # override: experiments only
 
 OK, ERR_INVALID, ERR_NODEVICE, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
 DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2

@@ -243,35 +243,81 @@ FQ_DEV void store_r2_packed(u64* w, const R2& t) {
     store_fe2(w, t.N); store_fe2(w + 4, t.D); store_fe2(w + 8, t.E); store_fe2(w + 12, t.F);
 }
 
-// Working form of a table entry: 40 limbs (tight) = 10 x uint4, in HBM scratch or LDS.
-constexpr int R2_LIMBS = 40;
-template <typename P> FQ_DEV R2 load_r2_limbs(const P* src) {   // src: uint4-aligned u32 pointer
+// Working form of a table entry in HBM scratch or LDS: four coordinates (N, D, E, F) of 12 dwords
+// each (10 tight limbs re|im + 2 pad, so that every coordinate is three aligned 16-byte accesses).
+constexpr int COORD_U32 = 12;
+constexpr int R2_LIMBS = 4 * COORD_U32;
+template <typename P> FQ_DEV Fe2<1> load_fe2_limbs(const P* src) {   // src: 16-byte aligned u32 pointer
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    uint4 a = q[0], b = q[1], c = q[2];
+    Fe2<1> r;
+    r.re.l[0] = a.x; r.re.l[1] = a.y; r.re.l[2] = a.z; r.re.l[3] = a.w; r.re.l[4] = b.x;
+    r.im.l[0] = b.y; r.im.l[1] = b.z; r.im.l[2] = b.w; r.im.l[3] = c.x; r.im.l[4] = c.y;
+    return r;
+}
+template <typename P> FQ_DEV void store_fe2_limbs(P* dst, const Fe2<1>& v) {
+    uint4* q = reinterpret_cast<uint4*>(dst);
+    q[0] = make_uint4(v.re.l[0], v.re.l[1], v.re.l[2], v.re.l[3]);
+    q[1] = make_uint4(v.re.l[4], v.im.l[0], v.im.l[1], v.im.l[2]);
+    q[2] = make_uint4(v.im.l[3], v.im.l[4], 0u, 0u);
+}
+template <typename P> FQ_DEV R2 load_r2_limbs(const P* src) {
     R2 t;
-    u32 v[R2_LIMBS];
-#pragma unroll
-    for (int i = 0; i < R2_LIMBS / 4; i++) {
-        uint4 q = reinterpret_cast<const uint4*>(src)[i];
-        v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
-    }
-    Fe2<1>* f = &t.N;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-#pragma unroll
-        for (int i = 0; i < 5; i++) { f[k].re.l[i] = v[10 * k + i]; f[k].im.l[i] = v[10 * k + 5 + i]; }
-    }
+    t.N = load_fe2_limbs(src); t.D = load_fe2_limbs(src + COORD_U32);
+    t.E = load_fe2_limbs(src + 2 * COORD_U32); t.F = load_fe2_limbs(src + 3 * COORD_U32);
     return t;
 }
 template <typename P> FQ_DEV void store_r2_limbs(P* dst, const R2& t) {
-    u32 v[R2_LIMBS];
-    const Fe2<1>* f = &t.N;
+    store_fe2_limbs(dst, t.N); store_fe2_limbs(dst + COORD_U32, t.D);
+    store_fe2_limbs(dst + 2 * COORD_U32, t.E); store_fe2_limbs(dst + 3 * COORD_U32, t.F);
+}
+
+// -x if mask == ~0 else x, branch-free in two cheap ops per limb: bias - x == (bias + 1) + ~x (mod 2^32)
+template <int B> FQ_DEV Fe<B + 1> fe_cneg(const Fe<B>& x, u32 mask) {
+    static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");
+    Fe<B + 1> r;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-#pragma unroll
-        for (int i = 0; i < 5; i++) { v[10 * k + i] = f[k].re.l[i]; v[10 * k + 5 + i] = f[k].im.l[i]; }
-    }
-#pragma unroll
-    for (int i = 0; i < R2_LIMBS / 4; i++)
-        reinterpret_cast<uint4*>(dst)[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    for (int i = 0; i < 5; i++) r.l[i] = (x.l[i] ^ mask) + ((bias_limb(B + 1, i) + 1u) & mask);
+    return r;
+}
+template <int B> FQ_DEV Fe2<B + 1> fe2_cneg(const Fe2<B>& x, u32 mask) {
+    Fe2<B + 1> r; r.re = fe_cneg(x.re, mask); r.im = fe_cneg(x.im, mask); return r;
+}
+
+// Q + (+-T) for a table entry T read coordinate by coordinate from `entry` (HBM scratch or LDS):
+// ADD(Q, selectpt(s, T, R2neg(T))) of curve4q.py:232-233, :440 with R2neg(T) = (D, N, E, -F).  The N/D swap
+// of the negated entry is an address choice, -F is a two-op conditional negation, and each coordinate
+// is loaded just before the product that consumes it, which keeps the live set near 100 VGPRs.
+template <typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_mask) {
+    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
+    Fe2<1> T = fe2_mul(q.Ta, q.Tb);                          // R1toR3: curve4q.py:119-126
+    Fe2<2> N1 = fe2_add(q.X, q.Y);
+    Fe2<3> D1 = fe2_sub(q.Y, q.X);
+    Fe2<1> A = fe2_mul(D1, load_fe2_limbs(entry + off_d));    // ADD_core: curve4q.py:155-171
+    Fe2<1> B = fe2_mul(N1, load_fe2_limbs(entry + off_n));
+    Fe2<1> C = fe2_mul(fe2_cneg(load_fe2_limbs(entry + 3 * COORD_U32), neg_mask), T);
+    Fe2<1> D = fe2_mul(load_fe2_limbs(entry + 2 * COORD_U32), q.Z);
+    Fe2<3> E = fe2_sub(B, A);
+    Fe2<3> F = fe2_sub(D, C);
+    Fe2<2> G = fe2_add(D, C);
+    Fe2<2> H = fe2_add(B, A);
+    R1 r;
+    r.X = fe2_mul(E, F);
+    r.Y = fe2_mul(G, H);
+    r.Z = fe2_mul(F, G);
+    r.Ta = widen<4>(E);
+    r.Tb = H;
+    return r;
+}
+// R2toR4(selectpt(s, T, nT)): the ladder's starting point (curve4q.py:229, :437)
+template <typename P> FQ_DEV Proj<1, 1, 1> start_table(const P* entry, u32 neg_mask) {
+    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
+    Fe2<1> N = load_fe2_limbs(entry + off_n), D = load_fe2_limbs(entry + off_d);
+    Proj<1, 1, 1> r;
+    r.X = fe2_carry(fe2_sub(N, D));
+    r.Y = fe2_carry(fe2_add(D, N));
+    r.Z = load_fe2_limbs(entry + 2 * COORD_U32);
+    return r;
 }
 
 }  // namespace fq

@@ -29,9 +29,12 @@ using namespace fq;
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int SLOT_U32 = 384;          // per-lane scratch: 8 table entries (320) + P.xyz (30) + Q.xyz (30), padded
-constexpr int SLOT_P = 320, SLOT_Q = 352;
-constexpr int LDS_ENTRY_U32 = 44;      // 40 limbs + 4 pad: entry k starts at bank 44k mod 64 -> conflict-free b128 gathers
+#ifndef FQ_WAVES_PER_EU
+#define FQ_WAVES_PER_EU 1
+#endif
+constexpr int SLOT_U32 = 464;          // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
+constexpr int SLOT_P = 384, SLOT_Q = 424;
+constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
 
 enum Algo { ENDO = 0, WINDOWED = 1 };
 
@@ -112,29 +115,27 @@ FQ_DEV void build_table_endo(const R1& P, u32* slot) {
 
 // ---- the ladders -------------------------------------------------------------------------------
 template <typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
-    R2 t = load_r2_limbs(tbl + (e.top & 7) * stride);
-    Proj<1, 1, 1> q4 = r2_to_r4(as_signed(t));        // s[64] = 1: the entry itself
+    Proj<1, 1, 1> q4 = start_table(tbl + (e.top & 7) * stride, 0u);        // s[64] = 1: the entry itself
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
-        t = load_r2_limbs(tbl + endo_digit(e, i) * stride);
+        const TP* entry = tbl + endo_digit(e, i) * stride;
         Q = dbl(Q.X, Q.Y, Q.Z);
-        Q = add(Q, r2_apply_sign(t, endo_neg_mask(e, i)));
+        Q = add_table(Q, entry, endo_neg_mask(e, i));
     }
     return Q;
 }
 template <typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
-    R2 t = load_r2_limbs(tbl + (code & 7) * stride);
-    Proj<1, 1, 1> q4 = r2_to_r4(r2_apply_sign(t, (code >> 3) - 1u));
+    Proj<1, 1, 1> q4 = start_table(tbl + (code & 7) * stride, (code >> 3) - 1u);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
         code = win_code_from_window(win_window(w, i));
-        t = load_r2_limbs(tbl + (code & 7) * stride);
+        const TP* entry = tbl + (code & 7) * stride;
 #pragma unroll 1
         for (int k = 0; k < 4; k++) Q = dbl(Q.X, Q.Y, Q.Z);
-        Q = add(Q, r2_apply_sign(t, (code >> 3) - 1u));
+        Q = add_table(Q, entry, (code >> 3) - 1u);
     }
     return Q;
 }
@@ -148,7 +149,7 @@ FQ_DEV void load_scalar(const u64* p, u64 m[4]) {
 
 // ALGO: ENDO / WINDOWED.  FIXED: shared table in LDS.  DH: affine in, cofactor clearing, affine out + status.
 template <int ALGO, bool FIXED, bool DH>
-__global__ __launch_bounds__(BLOCK) void ladder_kernel(LadderArgs a) {
+__global__ __launch_bounds__(BLOCK, FQ_WAVES_PER_EU) void ladder_kernel(LadderArgs a) {
     __shared__ __attribute__((aligned(16))) u32 lds_table[FIXED ? 8 * LDS_ENTRY_U32 : 4];
     if (FIXED) {
         for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
