@@ -23,9 +23,9 @@ sys.path.insert(0, ROOT)
 
 BATCH = 1 << 16                      # BASELINE.json configs[1]
 BYTES_PER_OP = 32 + 160 + 160        # scalar + R1 in + R1 out
-MADS_PER_OP = 100_000                # v_mad_u64_u32 issued per variable-base MUL_endo by this implementation
+MADS_PER_OP = 100_100                # v_mad_u64_u32 issued per variable-base MUL_endo by this implementation
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md
-VALU_MAD_PEAK = 1024 * 64 / 3.32 * 2.4e9   # measured: one wave64 v_mad_u64_u32 per 3.32 cycles per SIMD (profiles/valu_rates_r01.txt)
+VALU_MAD_PEAK = 1024 * 64 / 4.0 * 2.4e9    # measured: a wave64 v_mad_u64_u32 occupies a SIMD for 4 cycles (profiles/true_rates_r01.txt)
 
 
 def seeded_scalars(seed, n):

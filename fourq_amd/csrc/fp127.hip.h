@@ -4,19 +4,19 @@
 //   GFp.add/sub/mul/sqr/neg/inv      bifurcation/fourq impl/fields.py:29-106
 //   GFp2.add/sub/mul/sqr/neg/conj/inv impl/fields.py:156-199
 //
-// Representation (chosen from tools/microbench/valu_rates.hip measurements on MI355X: carry-chain
-// and 3-operand instructions cost 2.4x a plain 32-bit add, v_mad_u64_u32 accumulating in place
-// costs the same as any other "slow" op): five 26-bit limbs in 32-bit registers, radix 2^26,
+// Representation (chosen from tools/microbench measurements on MI355X, profiles/true_rates_r01.txt:
+// per SIMD a wave64 v_mad_u64_u32 takes 4 cycles, every other 64-bit or carry-propagating op ~3.7, a
+// plain 32-bit VOP2 op ~2; so carries, not multiplies, are what to avoid): five 26-bit limbs in 32-bit registers, radix 2^26,
 // 130 bits, 2^130 == 8 (mod p).  Limbs are kept LAZILY: adds and subtractions are five plain
 // v_add_u32 / v_sub_u32 with no carry propagation; only multiplications normalise.  Every element
 // type carries a compile-time bound B meaning "each limb <= B * UNIT" (UNIT = 2^26 + 2^15), and
 // every multiplication static_asserts that its 64-bit column accumulators cannot overflow, so the
 // laziness is verified by the compiler, not by hope.
 //
-// A GF(p) product is 25 v_mad_u64_u32 accumulating into five 64-bit columns (the wrap-around
-// terms use the second operand pre-multiplied by 8); a GF(p^2) product accumulates its two GF(p)
-// products per component into the same columns (a0*b0 + (-a1)*b1 and a0*b1 + a1*b0), so it costs
-// 100 multiply-adds and only two normalisations.
+// A GF(p) product is 25 v_mad_u64_u32 accumulating into 64-bit columns (the wrap-around terms use
+// the second operand pre-multiplied by 8); a GF(p^2) product accumulates its two GF(p) products per
+// component into the same columns (a0*b0 + (-a1)*b1 and a0*b1 + a1*b0): 100 multiply-adds and two
+// carry passes (per limb one 64-bit shift, one mask, one 64-bit add).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -81,24 +81,6 @@ template <int B> FQ_DEV Fe<B + 1> fe_neg(const Fe<B>& b) {
 }
 template <int B> FQ_DEV Fe<2 * B> fe_dbl(const Fe<B>& a) { return fe_add(a, a); }
 
-// ---- normalisation of five 64-bit columns ----------------------------------------------------
-// Input: value = sum c[k] * 2^(26k), each c[k] + incoming carry < 2^64.
-// Output: limbs 0,2,3,4 < 2^26 and limb 1 < 2^26 + 2^15  (i.e. bound 1).
-FQ_DEV Fe<1> fe_normalize(u64 c0, u64 c1, u64 c2, u64 c3, u64 c4) {
-    Fe<1> r;
-    c1 += c0 >> LIMB_BITS;
-    c2 += c1 >> LIMB_BITS;
-    c3 += c2 >> LIMB_BITS;
-    c4 += c3 >> LIMB_BITS;
-    u64 w = ((c4 >> LIMB_BITS) << 3) + ((u32)c0 & LIMB_MASK);   // 2^130 == 8 ; w < 2^42
-    r.l[0] = (u32)w & LIMB_MASK;
-    r.l[1] = ((u32)c1 & LIMB_MASK) + (u32)(w >> LIMB_BITS);
-    r.l[2] = (u32)c2 & LIMB_MASK;
-    r.l[3] = (u32)c3 & LIMB_MASK;
-    r.l[4] = (u32)c4 & LIMB_MASK;
-    return r;
-}
-
 // 32-bit carry pass: any bound -> bound 1 (15 cheap VALU ops).
 template <int B> FQ_DEV Fe<1> fe_carry(const Fe<B>& a) {
     static_assert((u64)B * UNIT + (1ull << 20) < (1ull << 32), "limb overflow");
@@ -119,34 +101,49 @@ template <int B> FQ_DEV Fe2<1> fe2_carry(const Fe2<B>& a) {
     Fe2<1> r; r.re = fe_carry(a.re); r.im = fe_carry(a.im); return r;
 }
 
-// ---- column multiply-accumulate ----------------------------------------------------------------
-// c[k] += sum_{i+j == k (mod 5)} a_i * (i+j < 5 ? b_j : 8*b_j) ; b8 = 8*b limbwise.
-struct Cols {
-    u64 c[5];
-};
-FQ_DEV void cols_zero(Cols& s) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) s.c[k] = 0;
-}
-FQ_DEV void cols_mac(Cols& s, const u32 a[5], const u32 b[5], const u32 b8[5]) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-#pragma unroll
-        for (int i = 0; i < 5; i++) {
-            int j = k - i;
-            u32 bj = (j >= 0) ? b[j] : b8[j + 5];
-            s.c[k] += (u64)a[i] * bj;   // v_mad_u64_u32, accumulating in place
-        }
-    }
-}
+// ---- column multiply-accumulate -------------------------------------------------------------------
+// Column k of a product is  sum_{i+j == k (mod 5)} a_i * (i+j < 5 ? b_j : 8*b_j).  Columns are
+// written in order with column k+1 starting from (column k >> 26); hipcc re-associates that into
+// five independent in-place v_mad_u64_u32 chains plus one v_lshl_add_u64 per limb for the carry,
+// which keeps the multiply-adds free of dependences on the carry chain (better for a lone wave).
 template <int B> FQ_DEV void times8(u32 out[5], const Fe<B>& b) {
     static_assert((u64)8 * B * UNIT < (1ull << 32), "8*b does not fit 32 bits");
 #pragma unroll
     for (int i = 0; i < 5; i++) out[i] = b.l[i] << 3;
 }
-// column bound: n products, each <= (A*UNIT) * (8*B*UNIT); plus normalisation carries (< 2^40)
-constexpr bool cols_ok(u64 weighted) {   // weighted = sum over accumulated products of A*B
+// column bound: `weighted` = sum over accumulated products of A*B (in UNIT^2), times 5 terms, times 8
+// for the wrap-around factor, plus the incoming carry (< 2^40)
+constexpr bool cols_ok(u64 weighted) {
     return weighted * 5 * 8 <= ((~0ull - (1ull << 41)) / (UNIT * UNIT));
+}
+template <int K> FQ_DEV u64 col_mac(u64 acc, const u32 a[5], const u32 b[5], const u32 b8[5]) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int j = K - i;
+        acc += (u64)a[i] * (j >= 0 ? b[j] : b8[j + 5]);   // v_mad_u64_u32, accumulating in place
+    }
+    return acc;
+}
+// five limbs (< 2^26 each) + the carry out of column 4 -> bound-1 element (2^130 == 8)
+FQ_DEV Fe<1> fe_finish(u32 l0, u32 l1, u32 l2, u32 l3, u32 l4, u64 top) {
+    Fe<1> r;
+    u64 w = (top << 3) + l0;                 // top < 2^38 -> w < 2^42
+    r.l[0] = (u32)w & LIMB_MASK;
+    r.l[1] = l1 + (u32)(w >> LIMB_BITS);     // <= 2^26 - 1 + 2^15 = UNIT - 1
+    r.l[2] = l2; r.l[3] = l3; r.l[4] = l4;
+    return r;
+}
+// sum of up to two GF(p) products  a*b + c*d  (pass c == nullptr for a single product)
+template <bool TWO> FQ_DEV Fe<1> fe_mac2(const u32 a[5], const u32 b[5], const u32 b8[5], const u32 c[5], const u32 d[5], const u32 d8[5]) {
+    u32 l[5];
+    u64 acc = 0;
+#define FQ_COL(K)                                                   \
+    acc = col_mac<K>(acc, a, b, b8);                                \
+    if (TWO) acc = col_mac<K>(acc, c, d, d8);                       \
+    l[K] = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    FQ_COL(0) FQ_COL(1) FQ_COL(2) FQ_COL(3) FQ_COL(4)
+#undef FQ_COL
+    return fe_finish(l[0], l[1], l[2], l[3], l[4], acc);
 }
 
 // ---- GF(p) multiplication ----------------------------------------------------------------------
@@ -154,24 +151,28 @@ template <int A, int B> FQ_DEV Fe<1> fe_mul(const Fe<A>& a, const Fe<B>& b) {   
     static_assert(cols_ok((u64)A * B), "column overflow");
     u32 b8[5];
     times8(b8, b);
-    Cols s; cols_zero(s);
-    cols_mac(s, a.l, b.l, b8);
-    return fe_normalize(s.c[0], s.c[1], s.c[2], s.c[3], s.c[4]);
+    return fe_mac2<false>(a.l, b.l, b8, nullptr, nullptr, nullptr);
 }
 template <int A> FQ_DEV Fe<1> fe_sqr(const Fe<A>& a) {                          // fields.py:48-51
     static_assert(cols_ok((u64)A * A), "column overflow");
-    static_assert((u64)16 * A * UNIT < (1ull << 32), "16*a does not fit 32 bits");
-    // 15 products: squares once, cross terms through a doubled operand
+    static_assert((u64)8 * A * UNIT < (1ull << 32), "8*a does not fit 32 bits");
+    // 15 products: squares once, cross terms through a doubled operand; e = 8a for the wrap-around
     const u32 *x = a.l;
-    u32 d[5], e[5];   // d = 2a, e = 8a (wrap-around), f = 16a (wrap-around and doubled)
+    u32 d[5], e[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) { d[i] = x[i] << 1; e[i] = x[i] << 3; }
-    u64 c0 = (u64)x[0] * x[0] + (u64)d[1] * (e[4]) + (u64)d[2] * e[3];
-    u64 c1 = (u64)d[0] * x[1] + (u64)d[2] * e[4] + (u64)x[3] * e[3];
-    u64 c2 = (u64)d[0] * x[2] + (u64)x[1] * x[1] + (u64)d[3] * e[4];
-    u64 c3 = (u64)d[0] * x[3] + (u64)d[1] * x[2] + (u64)x[4] * e[4];
-    u64 c4 = (u64)d[0] * x[4] + (u64)d[1] * x[3] + (u64)x[2] * x[2];
-    return fe_normalize(c0, c1, c2, c3, c4);
+    u32 l0, l1, l2, l3, l4;
+    u64 acc = (u64)x[0] * x[0] + (u64)d[1] * e[4] + (u64)d[2] * e[3];
+    l0 = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    acc += (u64)d[0] * x[1] + (u64)d[2] * e[4] + (u64)x[3] * e[3];
+    l1 = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    acc += (u64)d[0] * x[2] + (u64)x[1] * x[1] + (u64)d[3] * e[4];
+    l2 = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    acc += (u64)d[0] * x[3] + (u64)d[1] * x[2] + (u64)x[4] * e[4];
+    l3 = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    acc += (u64)d[0] * x[4] + (u64)d[1] * x[3] + (u64)x[2] * x[2];
+    l4 = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    return fe_finish(l0, l1, l2, l3, l4, acc);
 }
 
 // ---- GF(p^2) -----------------------------------------------------------------------------------
@@ -197,18 +198,8 @@ template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) 
     times8(b1x8, b.im);
     Fe<A + 1> na1 = fe_neg(a.im);
     Fe2<1> r;
-    {
-        Cols s; cols_zero(s);
-        cols_mac(s, a.re.l, b.re.l, b0x8);
-        cols_mac(s, na1.l, b.im.l, b1x8);
-        r.re = fe_normalize(s.c[0], s.c[1], s.c[2], s.c[3], s.c[4]);
-    }
-    {
-        Cols s; cols_zero(s);
-        cols_mac(s, a.re.l, b.im.l, b1x8);
-        cols_mac(s, a.im.l, b.re.l, b0x8);
-        r.im = fe_normalize(s.c[0], s.c[1], s.c[2], s.c[3], s.c[4]);
-    }
+    r.re = fe_mac2<true>(a.re.l, b.re.l, b0x8, na1.l, b.im.l, b1x8);
+    r.im = fe_mac2<true>(a.re.l, b.im.l, b1x8, a.im.l, b.re.l, b0x8);
     return r;
 }
 // (a0 + a1 i)^2 = (a0 + a1)(a0 - a1) + (2 a0 a1) i                               fields.py:176-181

@@ -114,3 +114,20 @@ def test_dh_symmetry_and_392_property(eng):
     direct = eng.prim("PT_R1TOAFFINE", eng.mul_windowed(m392, g1))
     dh, st = eng.dh_endo(a[:k], np.repeat(g.reshape(1, 8), k, axis=0))
     assert not st.any() and np.array_equal(dh, direct)
+
+
+def test_full_size_cfg4_shard_exchange_symmetry(eng):
+    """BASELINE.json config 4, one GPU's shard (2^19 of the 2^22 exchanges): DH(a, DH(b, G)) == DH(b, DH(a, G))
+    for every pair, the fixed-base and variable-base first halves agree, and a 2^12 slice matches the C oracle."""
+    n = 1 << 19
+    a, b = seeded_scalars(40002, n), seeded_scalars(40003, n)
+    g = codec.pack_point(G)
+    t392 = eng.table_endo(codec.pack_point(o.MUL_endo(392, o.AffineToR1(*G))))
+    ab, s1 = eng.dh_exchange(a, b, g, table392=t392)
+    ba, s2 = eng.dh_exchange(b, a, g)
+    assert not s1.any() and not s2.any() and np.array_equal(ab, ba)
+    k = 1 << 12
+    gk = np.repeat(g.reshape(1, 8), k, axis=0)
+    mid, st = oc.dh(oc.ENDO, b[:k], gk)
+    want, st2 = oc.dh(oc.ENDO, a[:k], mid)
+    assert not st.any() and not st2.any() and np.array_equal(ab[:k], want)

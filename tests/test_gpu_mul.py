@@ -164,3 +164,18 @@ def test_device_pointer_api_matches_host_api(eng):
     finally:
         eng.set_stream(None)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), eng.mul_endo(s, pts))
+
+
+def test_full_size_cfg5_mixed_vs_c_oracle(eng):
+    """BASELINE.json config 5 at its full size: 2^20 elements, 50% fixed-base / 50% variable-base by a
+    seeded bitstream, every output compared with the C oracle."""
+    n = 1 << 20
+    s = seeded_scalars(50002, n)
+    pts = torsion_points(eng, 50003, n)
+    flags = (np.frombuffer(random.Random(50004).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
+    tbl = eng.table_endo(codec.pack_point(G1))
+    got = eng.mul_endo_mixed(s, pts, flags, tbl)
+    want = oc.mul(oc.ENDO, s, None, tbl)
+    var = np.flatnonzero(flags)
+    want[var] = oc.mul(oc.ENDO, s[var], pts[var])
+    assert 0.49 < flags.mean() < 0.51 and np.array_equal(got, want)
