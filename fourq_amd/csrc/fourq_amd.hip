@@ -29,14 +29,17 @@ using namespace fq;
 namespace {
 
 constexpr int BLOCK = 256;
-#ifndef FQ_WAVES_PER_EU
-#define FQ_WAVES_PER_EU 1
-#endif
 constexpr int SLOT_U32 = 464;          // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
 constexpr int SLOT_P = 384, SLOT_Q = 424;
 constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
 
 enum Algo { ENDO = 0, WINDOWED = 1 };
+// where the ladder finds its table:
+//   FUSED     built by the same lane into its scratch slot just before the ladder (small batches: one launch)
+//   LDS       one shared table staged into LDS (fixed base)
+//   PREBUILT  built per element by prep_kernel into scratch slot `pos` (large batches: the ladder kernel then
+//             fits 128 VGPRs and runs 4 waves per SIMD instead of 1)
+enum Src { FUSED = 0, LDS = 1, PREBUILT = 2 };
 
 struct LadderArgs {
     const u64* scalars;    // n x 4
@@ -44,6 +47,7 @@ struct LadderArgs {
     u64* out;              // n x 20 (R1) or n x 8 (affine, DH)
     uint8_t* status;       // DH only
     const u32* index;      // optional: element ids to process (mixed batches); NULL = identity
+    u32 base;              // first position of this launch (chunked large batches)
     const u32* table;      // fixed base: 8 x 40 limbs (global), staged to LDS
     u32* scratch;          // variable base: SLOT_U32 per resident lane
     u32 n;
@@ -147,48 +151,72 @@ FQ_DEV void load_scalar(const u64* p, u64 m[4]) {
     m[2] = (u64)b.x | ((u64)b.y << 32); m[3] = (u64)b.z | ((u64)b.w << 32);
 }
 
-// ALGO: ENDO / WINDOWED.  FIXED: shared table in LDS.  DH: affine in, cofactor clearing, affine out + status.
-template <int ALGO, bool FIXED, bool DH>
-__global__ __launch_bounds__(BLOCK, FQ_WAVES_PER_EU) void ladder_kernel(LadderArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 lds_table[FIXED ? 8 * LDS_ENTRY_U32 : 4];
-    if (FIXED) {
+// Large variable-base batches, first half: per element, (DH: membership test, cofactor clearing,) table
+// construction into scratch slot `pos`.  Kept apart from the ladder so that the endomorphisms' register
+// appetite (256 VGPRs) does not set the ladder's occupancy.
+template <int ALGO, bool DH>
+__global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
+    const u32 pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= a.n) return;
+    const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
+    R1 P;
+    if (DH) {
+        Fe2<1> x = load_fe2(a.points + 8 * (size_t)id), y = load_fe2(a.points + 8 * (size_t)id + 4);
+        a.status[id] = point_on_curve(x, y) ? FOURQ_DH_OK : FOURQ_DH_NOT_ON_CURVE;
+        P = clear_cofactor_392(x, y);
+    } else {
+        P = load_r1(a.points + 20 * (size_t)id);
+    }
+    u32* slot = a.scratch + (size_t)pos * SLOT_U32;
+    if (ALGO == ENDO) build_table_endo(P, slot); else build_table_windowed(P, slot);
+}
+
+// ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
+template <int ALGO, int SRC, bool DH>
+__global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : 4];
+    if (SRC == LDS) {
         for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
             lds_table[(i / R2_LIMBS) * LDS_ENTRY_U32 + (i % R2_LIMBS)] = a.table[i];
         __syncthreads();
     }
     const u32 lane_slot = blockIdx.x * BLOCK + threadIdx.x;
     const u32 lanes = gridDim.x * BLOCK;
-    u32* slot = FIXED ? nullptr : a.scratch + (size_t)lane_slot * SLOT_U32;
     const u32 n_round = (a.n + BLOCK - 1) / BLOCK * BLOCK;
 #pragma unroll 1
     for (u32 it = lane_slot; it < n_round; it += lanes) {
         const bool live = it < a.n;
         const u32 pos = live ? it : a.n - 1;              // idle tail lanes redo the last element, store nothing
-        const u32 id = a.index ? a.index[pos] : pos;
+        const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
+        u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * SLOT_U32;
 
         uint8_t st = FOURQ_DH_OK;
-        R1 P;
-        if (DH) {
-            Fe2<1> x = load_fe2(a.points + 8 * (size_t)id), y = load_fe2(a.points + 8 * (size_t)id + 4);
-            if (!point_on_curve(x, y)) st = FOURQ_DH_NOT_ON_CURVE;     // keep going branch-free; masked at the end
-            if (!FIXED) P = clear_cofactor_392(x, y);                   // with a table the reference discards [392]P (curve4q.py:209)
-        } else if (!FIXED) {
-            P = load_r1(a.points + 20 * (size_t)id);
-        }
-        if (!FIXED) {
-            if (ALGO == ENDO) build_table_endo(P, slot); else build_table_windowed(P, slot);
+        if (SRC == PREBUILT) {
+            if (DH) st = a.status[id];                                  // membership verdict of prep_kernel
+        } else {
+            R1 P;
+            if (DH) {
+                Fe2<1> x = load_fe2(a.points + 8 * (size_t)id), y = load_fe2(a.points + 8 * (size_t)id + 4);
+                if (!point_on_curve(x, y)) st = FOURQ_DH_NOT_ON_CURVE;  // keep going branch-free; masked at the end
+                if (SRC == FUSED) P = clear_cofactor_392(x, y);         // with a table the reference discards [392]P (curve4q.py:209)
+            } else if (SRC == FUSED) {
+                P = load_r1(a.points + 20 * (size_t)id);
+            }
+            if (SRC == FUSED) {
+                if (ALGO == ENDO) build_table_endo(P, slot); else build_table_windowed(P, slot);
+            }
         }
         R1 Q;
         if (ALGO == ENDO) {
             u64 v[4];
             decompose(m, v);
             EndoDigits e = recode(v);
-            Q = FIXED ? ladder_endo(e, lds_table, LDS_ENTRY_U32) : ladder_endo(e, slot, R2_LIMBS);
+            Q = SRC == LDS ? ladder_endo(e, lds_table, LDS_ENTRY_U32) : ladder_endo(e, slot, R2_LIMBS);
         } else {
             WinScalar w = win_reduce(m);
-            Q = FIXED ? ladder_windowed(w, lds_table, LDS_ENTRY_U32) : ladder_windowed(w, slot, R2_LIMBS);
+            Q = SRC == LDS ? ladder_windowed(w, lds_table, LDS_ENTRY_U32) : ladder_windowed(w, slot, R2_LIMBS);
         }
         if (DH) {
             Fe2<1> ax, ay;
@@ -347,8 +375,12 @@ struct fourq_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int cus = 0;
-    size_t lanes = 0;              // resident lanes the ladder kernels are launched with
-    u32* scratch = nullptr;        // lanes x SLOT_U32
+    size_t lanes = 0;              // resident lanes of the fused variable-base kernels (1 wave per SIMD)
+    size_t lanes_w4 = 0;           // resident lanes of the 128-VGPR kernels (4 waves per SIMD)
+    size_t split_min = 0;          // variable-base batches of at least this many elements take the prep + ladder route
+    size_t split_chunk = 0;        // elements per prep + ladder round (<= lanes_w4)
+    bool split_all = false;        // FOURQ_SPLIT_ALL=1: also route plain MUL_endo through prep + ladder (tests)
+    u32* scratch = nullptr;        // max(lanes, lanes_w4) x SLOT_U32
     u32* table_limbs = nullptr;    // 8 x 40
     u64* table_packed = nullptr;   // 128 words
     u32* part_counters = nullptr;  // 2
@@ -380,15 +412,36 @@ int ensure_stage(fourq_ctx* c, size_t bytes) {
     return FOURQ_OK;
 }
 
-template <int ALGO, bool FIXED, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs a) {
+template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs a) {
     if (a.n == 0) return FOURQ_OK;
     size_t blocks_needed = ((size_t)a.n + BLOCK - 1) / BLOCK;
-    size_t blocks_max = c->lanes / BLOCK;
+    size_t blocks_max = (SRC == FUSED ? c->lanes : c->lanes_w4) / BLOCK;
     unsigned grid = (unsigned)(blocks_needed < blocks_max ? blocks_needed : blocks_max);
     a.scratch = c->scratch;
     a.table = c->table_limbs;
-    hipLaunchKernelGGL((ladder_kernel<ALGO, FIXED, DH>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL((ladder_kernel<ALGO, SRC, DH>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+// variable base: one fused launch for small batches, prep + ladder per chunk of lanes_w4 elements for large ones
+// Measured on MI355X at 2^20 elements (gpurun_out/probe_chunk.txt): the two-kernel route gains 7-8 % for
+// MUL_windowed and DH_* but loses 7 % for plain MUL_endo, whose 64-step ladder is too short to amortise the
+// second launch and the colder table gathers (4 waves per SIMD put 486 MB of tables in flight, past the
+// Infinity Cache); so plain MUL_endo always stays fused.
+template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
+    const bool split = (ALGO == WINDOWED || DH || c->split_all) && a.n >= c->split_min;
+    if (!split) return launch_ladder<ALGO, FUSED, DH>(c, a);
+    const u32 total = a.n;
+    for (u32 off = 0; off < total; off += (u32)c->split_chunk) {
+        LadderArgs part = a;
+        part.base = a.base + off;
+        part.n = total - off < (u32)c->split_chunk ? total - off : (u32)c->split_chunk;
+        part.scratch = c->scratch;
+        hipLaunchKernelGGL((prep_kernel<ALGO, DH>), dim3((part.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, part);
+        HIP_TRY(c, hipGetLastError());
+        int rc = launch_ladder<ALGO, PREBUILT, DH>(c, part);
+        if (rc) return rc;
+    }
     return FOURQ_OK;
 }
 
@@ -406,10 +459,10 @@ int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
     DeviceGuard g(c->device);
     LadderArgs a = {};
     a.scalars = scalars; a.points = points; a.out = out; a.index = index; a.n = (u32)n;
-    if (points) return algo == ENDO ? launch_ladder<ENDO, false, false>(c, a) : launch_ladder<WINDOWED, false, false>(c, a);
+    if (points) return algo == ENDO ? launch_variable<ENDO, false>(c, a) : launch_variable<WINDOWED, false>(c, a);
     int rc = stage_table(c, table);
     if (rc) return rc;
-    return algo == ENDO ? launch_ladder<ENDO, true, false>(c, a) : launch_ladder<WINDOWED, true, false>(c, a);
+    return algo == ENDO ? launch_ladder<ENDO, LDS, false>(c, a) : launch_ladder<WINDOWED, LDS, false>(c, a);
 }
 
 int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
@@ -419,10 +472,10 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
     DeviceGuard g(c->device);
     LadderArgs a = {};
     a.scalars = scalars; a.points = points; a.out = out; a.status = status; a.n = (u32)n;
-    if (!table) return algo == ENDO ? launch_ladder<ENDO, false, true>(c, a) : launch_ladder<WINDOWED, false, true>(c, a);
+    if (!table) return algo == ENDO ? launch_variable<ENDO, true>(c, a) : launch_variable<WINDOWED, true>(c, a);
     int rc = stage_table(c, table);
     if (rc) return rc;
-    return algo == ENDO ? launch_ladder<ENDO, true, true>(c, a) : launch_ladder<WINDOWED, true, true>(c, a);
+    return algo == ENDO ? launch_ladder<ENDO, LDS, true>(c, a) : launch_ladder<WINDOWED, LDS, true>(c, a);
 }
 
 // host-pointer wrappers: one staging buffer carved into [scalars | points | out | status]
@@ -512,13 +565,20 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
     do {
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
         c->stream = c->own_stream;
-        // resident blocks per CU: the minimum over the variable-base kernels (they own the scratch)
+        // resident blocks per CU of the fused variable-base kernels (they own the per-lane scratch slots)
         int occ = 8, o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<ENDO, false, false>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<WINDOWED, false, true>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<ENDO, FUSED, false>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<WINDOWED, FUSED, true>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
         if (const char* env = getenv("FOURQ_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) occ = v; }
         c->lanes = (size_t)c->cus * occ * BLOCK;
-        if (hipMalloc(&c->scratch, c->lanes * SLOT_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        c->lanes_w4 = (size_t)c->cus * 4 * BLOCK;
+        c->split_min = 2 * c->lanes;                       // below two full waves of fused work the second launch does not pay
+        if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
+        if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
+        c->split_chunk = c->lanes_w4;
+        if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }
+        size_t slots = c->lanes > c->lanes_w4 ? c->lanes : c->lanes_w4;
+        if (hipMalloc(&c->scratch, slots * SLOT_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_counters, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }

@@ -179,3 +179,18 @@ def test_full_size_cfg5_mixed_vs_c_oracle(eng):
     var = np.flatnonzero(flags)
     want[var] = oc.mul(oc.ENDO, s[var], pts[var])
     assert 0.49 < flags.mean() < 0.51 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [131071, 131072, 262144 + 77])
+def test_prep_plus_ladder_route_boundaries(n, monkeypatch):
+    """Large variable-base MUL_windowed / DH batches take the two-kernel route (prep_kernel +
+    ladder_kernel<PREBUILT>) in chunks of the resident lane count; FOURQ_SPLIT_ALL=1 sends MUL_endo through it
+    too.  Sizes just below / at the switch and just past one chunk; outputs vs the C oracle."""
+    from fourq_amd import Engine
+    monkeypatch.setenv("FOURQ_SPLIT_ALL", "1")
+    with Engine(0) as eng:
+        s = seeded_scalars(4100 + n % 97, n)
+        pts = torsion_points(eng, 4200 + n % 89, n)
+        assert np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
+        k = 20000
+        assert np.array_equal(eng.mul_windowed(s, pts)[-k:], oc.mul(oc.WINDOWED, s[-k:], pts[-k:]))
