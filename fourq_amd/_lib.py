@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("FOURQ_AMD_LIB") or os.path.join(HERE, "libfourq_amd.s
 
 OK, ERR_INVALID, ERR_NODEVICE, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
 DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
+DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3
 
 u64p = POINTER(c_uint64)
 u8p = POINTER(c_uint8)
@@ -43,13 +44,17 @@ PROTOTYPES = {
     "fourq_dh_windowed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_endo_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_windowed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_encode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_decode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_decode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_prim_words": (c_int, [c_int, POINTER(c_size_t), POINTER(c_size_t)]),
     "fourq_prim_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t]),
 }
 
 # enum fourq_prim
 PRIM = {
-    "FP_ADD": 0, "FP_SUB": 1, "FP_MUL": 2, "FP_SQR": 3, "FP_NEG": 4, "FP_INV": 5,
+    "FP_ADD": 0, "FP_SUB": 1, "FP_MUL": 2, "FP_SQR": 3, "FP_NEG": 4, "FP_INV": 5, "FP_INVSQRT": 6,
     "FP2_ADD": 16, "FP2_SUB": 17, "FP2_MUL": 18, "FP2_SQR": 19, "FP2_NEG": 20, "FP2_CONJ": 21, "FP2_INV": 22,
     "PT_DBL": 32, "PT_ADD": 33, "PT_ADD_CORE": 34, "PT_R1TOR2": 35, "PT_R1TOR3": 36, "PT_R2TOR4": 37,
     "PT_TAU": 38, "PT_TAU_DUAL": 39, "PT_UPSILON": 40, "PT_CHI": 41, "PT_PHI": 42, "PT_PSI": 43,

@@ -219,6 +219,64 @@ FQ_DEV void r1_to_affine(const R1& p, Fe2<1>& x, Fe2<1>& y) {                   
     y = fe2_mul(p.Y, zi);
 }
 
+template <int B> FQ_DEV void store_fe2_words(u64* w, const Fe2<B>& a) {   // canonical 4 x u64
+    fe_canon(a.re, w[0], w[1]); fe_canon(a.im, w[2], w[3]);
+}
+// ---- point compression -----------------------------------------------
+// sign(X) of curve4q.py:33-39 on canonical words: top bit (bit 126) of x0, or of x1 when x0 == 0.
+FQ_DEV u32 fe2_sign(const u64 w[4]) {
+    return (w[0] | w[1]) ? (u32)(w[1] >> 62) & 1 : (u32)(w[3] >> 62) & 1;
+}
+// encode(X, Y) of curve4q.py:41-46: y0 | y1 little-endian, sign(x) in the top bit of the last byte.
+FQ_DEV void point_encode(const Fe2<1>& x, const Fe2<1>& y, u64 out[4]) {
+    u64 xw[4];
+    store_fe2_words(xw, x);
+    store_fe2_words(out, y);
+    out[3] |= (u64)fe2_sign(xw) << 63;
+}
+constexpr int DECODE_OK = 0, DECODE_RESERVED = 1, DECODE_NOT_ON_CURVE = 2, DECODE_REF_ATTRIBUTE_ERROR = 3;
+// decode(B) of curve4q.py:49-96.  Returns a DECODE_* status; (x, y) valid when DECODE_OK.
+//   RESERVED            "Malformed point: reserved bit is not zero" (:53, :62)
+//   NOT_ON_CURVE        "Point not on curve" (:94)
+//   REF_ATTRIBUTE_ERROR the reference's t == 0 branch (:76-77) names a GFp.two that does not exist and raises
+//                       AttributeError (e.g. for the encoding of the neutral point); reported, not "fixed"
+FQ_DEV int point_decode(const u64 in[4], Fe2<1>& x, Fe2<1>& y) {
+    const u64 HI = 0x7fffffffffffffffull;
+    int st = DECODE_OK;
+    if (in[1] >> 63) st = DECODE_RESERVED;
+    const u32 s = (u32)(in[3] >> 63);
+    const u64 y1hi = in[3] & HI;
+    if ((in[0] == ~0ull && in[1] == HI) || (in[2] == ~0ull && y1hi == HI)) st = DECODE_RESERVED;   // y0 >= p or y1 >= p
+    y.re = fe_unpack(in[0], in[1] & HI);
+    y.im = fe_unpack(in[2], y1hi);
+    Fe2<1> y2 = fe2_sqr(y);
+    Fe2<3> u = fe2_sub(y2, fe2_one());
+    Fe2<2> v = fe2_add(fe2_mul(y2, c_d()), fe2_one());
+    Fe<1> u0 = fe_carry(u.re), u1 = fe_carry(u.im), v0 = fe_carry(v.re), v1 = fe_carry(v.im);
+    Fe<1> t0 = fe_carry(fe_add(fe_mul(u0, v0), fe_mul(u1, v1)));
+    Fe<1> t1 = fe_carry(fe_sub(fe_mul(u1, v0), fe_mul(u0, v1)));
+    Fe<1> t2 = fe_carry(fe_add(fe_sqr(v0), fe_sqr(v1)));
+    Fe<1> t3 = fe_carry(fe_add(fe_sqr(t0), fe_sqr(t1)));
+    t3 = fe_mul(fe_invsqrt(t3), t3);
+    Fe<1> t = fe_carry(fe_dbl(fe_add(t0, t3)));
+    if (fe_is_zero(t) && st == DECODE_OK) st = DECODE_REF_ATTRIBUTE_ERROR;
+    Fe<1> a = fe_invsqrt(fe_mul(t, fe_mul(t2, fe_sqr(t2))));
+    Fe<1> at2 = fe_mul(a, t2);
+    Fe<1> b = fe_mul(at2, t);
+    Fe<1> x0 = fe_mul(b, fe_half());
+    Fe<1> x1 = fe_mul(at2, t1);
+    const u32 swap = fe_equal(t, fe_mul(t2, fe_sqr(b))) ? 0u : ~0u;
+    x.re = fe_select(swap, x1, x0);
+    x.im = fe_select(swap, x0, x1);
+    u64 xw[4];
+    store_fe2_words(xw, x);
+    x = fe2_carry(fe2_cneg(x, fe2_sign(xw) != s ? ~0u : 0u));
+    const u32 flip = point_on_curve(x, y) ? 0u : ~0u;                      // second candidate: conj(x)
+    x.im = fe_carry(fe_cneg(x.im, flip));
+    if (flip && !point_on_curve(x, y) && st == DECODE_OK) st = DECODE_NOT_ON_CURVE;
+    return st;
+}
+
 // ---- memory forms ------------------------------------------------------------------------------
 // C-ABI form: 128-bit little-endian words (fields packed, canonical on output).
 FQ_DEV Fe2<1> load_fe2(const u64* w) {
@@ -270,18 +328,6 @@ template <typename P> FQ_DEV R2 load_r2_limbs(const P* src) {
 template <typename P> FQ_DEV void store_r2_limbs(P* dst, const R2& t) {
     store_fe2_limbs(dst, t.N); store_fe2_limbs(dst + COORD_U32, t.D);
     store_fe2_limbs(dst + 2 * COORD_U32, t.E); store_fe2_limbs(dst + 3 * COORD_U32, t.F);
-}
-
-// -x if mask == ~0 else x, branch-free in two cheap ops per limb: bias - x == (bias + 1) + ~x (mod 2^32)
-template <int B> FQ_DEV Fe<B + 1> fe_cneg(const Fe<B>& x, u32 mask) {
-    static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");
-    Fe<B + 1> r;
-#pragma unroll
-    for (int i = 0; i < 5; i++) r.l[i] = (x.l[i] ^ mask) + ((bias_limb(B + 1, i) + 1u) & mask);
-    return r;
-}
-template <int B> FQ_DEV Fe2<B + 1> fe2_cneg(const Fe2<B>& x, u32 mask) {
-    Fe2<B + 1> r; r.re = fe_cneg(x.re, mask); r.im = fe_cneg(x.im, mask); return r;
 }
 
 // Q + (+-T) for a table entry T read coordinate by coordinate from `entry` (HBM scratch or LDS):

@@ -264,6 +264,34 @@ __global__ void partition_kernel(const uint8_t* flags, u32 n, u32* idx, u32* cou
     else idx[n - 1 - atomicAdd(&counters[1], 1u)] = i;
 }
 
+// ---- point compression ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void encode_kernel(const u64* affine, u64* out, u32 n) {
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u64 w[4];
+    point_encode(load_fe2(affine + 8 * (size_t)i), load_fe2(affine + 8 * (size_t)i + 4), w);
+    uint4* dst = reinterpret_cast<uint4*>(out + 4 * (size_t)i);
+    dst[0] = make_uint4((u32)w[0], (u32)(w[0] >> 32), (u32)w[1], (u32)(w[1] >> 32));
+    dst[1] = make_uint4((u32)w[2], (u32)(w[2] >> 32), (u32)w[3], (u32)(w[3] >> 32));
+}
+__global__ __launch_bounds__(BLOCK) void decode_kernel(const u64* in, u64* affine, uint8_t* status, u32 n) {
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u64 w[4];
+    load_scalar(in + 4 * (size_t)i, w);
+    Fe2<1> x, y;
+    int st = point_decode(w, x, y);
+    u64 o[8];
+    store_fe2_words(o, x); store_fe2_words(o + 4, y);
+    uint4* dst = reinterpret_cast<uint4*>(affine + 8 * (size_t)i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        u64 lo = st ? 0 : o[2 * k], hi = st ? 0 : o[2 * k + 1];
+        dst[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+    }
+    status[i] = (uint8_t)st;
+}
+
 // ---- primitives ----------------------------------------------------------------------------------
 FQ_DEV Fe<1> ld_fe(const u64* w) { return fe_unpack(w[0], w[1]); }
 template <int B> FQ_DEV void st_fe(u64* w, const Fe<B>& a) { fe_canon(a, w[0], w[1]); }
@@ -284,6 +312,7 @@ __global__ __launch_bounds__(64) void prim_kernel(int op, const u64* in, u64* ou
     case FOURQ_FP_SQR: st_fe(y, fe_sqr(ld_fe(x))); break;
     case FOURQ_FP_NEG: st_fe(y, fe_neg(ld_fe(x))); break;
     case FOURQ_FP_INV: st_fe(y, fe_inv(fe_carry(ld_fe(x)))); break;
+    case FOURQ_FP_INVSQRT: st_fe(y, fe_invsqrt(fe_carry(ld_fe(x)))); break;
     case FOURQ_FP2_ADD: store_fe2(y, fe2_add(load_fe2(x), load_fe2(x + 4))); break;
     case FOURQ_FP2_SUB: store_fe2(y, fe2_sub(load_fe2(x), load_fe2(x + 4))); break;
     case FOURQ_FP2_MUL: store_fe2(y, fe2_mul(load_fe2(x), load_fe2(x + 4))); break;
@@ -353,7 +382,7 @@ __global__ __launch_bounds__(64) void prim_kernel(int op, const u64* in, u64* ou
 
 struct PrimShape { int op; size_t in_words, out_words; };
 const PrimShape PRIMS[] = {
-    { FOURQ_FP_ADD, 4, 2 }, { FOURQ_FP_SUB, 4, 2 }, { FOURQ_FP_MUL, 4, 2 }, { FOURQ_FP_SQR, 4, 2 }, { FOURQ_FP_NEG, 4, 2 }, { FOURQ_FP_INV, 4, 2 },
+    { FOURQ_FP_ADD, 4, 2 }, { FOURQ_FP_SUB, 4, 2 }, { FOURQ_FP_MUL, 4, 2 }, { FOURQ_FP_SQR, 4, 2 }, { FOURQ_FP_NEG, 4, 2 }, { FOURQ_FP_INV, 4, 2 }, { FOURQ_FP_INVSQRT, 4, 2 },
     { FOURQ_FP2_ADD, 8, 4 }, { FOURQ_FP2_SUB, 8, 4 }, { FOURQ_FP2_MUL, 8, 4 }, { FOURQ_FP2_SQR, 8, 4 }, { FOURQ_FP2_NEG, 8, 4 },
     { FOURQ_FP2_CONJ, 8, 4 }, { FOURQ_FP2_INV, 8, 4 },
     { FOURQ_PT_DBL, 20, 20 }, { FOURQ_PT_ADD, 36, 20 }, { FOURQ_PT_ADD_CORE, 32, 20 }, { FOURQ_PT_R1TOR2, 20, 16 },
@@ -728,6 +757,52 @@ FQ_API int fourq_dh_endo_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64
 }
 FQ_API int fourq_dh_windowed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
     return dh_dev(c, WINDOWED, s, p, t, o, st, n);
+}
+
+FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {
+    if (!c || !affine || !out32 || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, affine, (u64*)out32, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+FQ_API int fourq_decode_batch_dev(fourq_ctx* c, const uint8_t* in32, uint64_t* affine, uint8_t* status, size_t n) {
+    if (!c || !in32 || !affine || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)in32, affine, status, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+FQ_API int fourq_encode_batch(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {
+    if (!c || !affine || !out32) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    int rc = ensure_stage(c, n * 96);
+    if (rc) return rc;
+    char* base = (char*)c->stage;
+    HIP_TRY(c, hipMemcpyAsync(base, affine, n * 64, hipMemcpyHostToDevice, c->stream));
+    rc = fourq_encode_batch_dev(c, (const uint64_t*)base, (uint8_t*)(base + n * 64), n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out32, base + n * 64, n * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+FQ_API int fourq_decode_batch(fourq_ctx* c, const uint8_t* in32, uint64_t* affine, uint8_t* status, size_t n) {
+    if (!c || !in32 || !affine || !status) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    int rc = ensure_stage(c, n * 97 + 16);
+    if (rc) return rc;
+    char* base = (char*)c->stage;
+    HIP_TRY(c, hipMemcpyAsync(base, in32, n * 32, hipMemcpyHostToDevice, c->stream));
+    rc = fourq_decode_batch_dev(c, (const uint8_t*)base, (uint64_t*)(base + n * 32), (uint8_t*)(base + n * 96), n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(affine, base + n * 32, n * 64, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(status, base + n * 96, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
 }
 
 FQ_API int fourq_prim_words(int op, size_t* in_words, size_t* out_words) {

@@ -267,6 +267,18 @@ template <int B> FQ_DEV Fe2<B> fe2_select(u32 mask, const Fe2<B>& x, const Fe2<B
     Fe2<B> r; r.re = fe_select(mask, x.re, y.re); r.im = fe_select(mask, x.im, y.im); return r;
 }
 
+// -x if mask == ~0 else x, branch-free in two cheap ops per limb: bias - x == (bias + 1) + ~x (mod 2^32)
+template <int B> FQ_DEV Fe<B + 1> fe_cneg(const Fe<B>& x, u32 mask) {
+    static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");
+    Fe<B + 1> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = (x.l[i] ^ mask) + ((bias_limb(B + 1, i) + 1u) & mask);
+    return r;
+}
+template <int B> FQ_DEV Fe2<B + 1> fe2_cneg(const Fe2<B>& x, u32 mask) {
+    Fe2<B + 1> r; r.re = fe_cneg(x.re, mask); r.im = fe_cneg(x.im, mask); return r;
+}
+
 // ---- inversion: x^(2^127-3) by the reference's fixed chain (fields.py:66-106) -----------------
 FQ_DEV Fe<1> fe_sqr_n(Fe<1> x, int n) {
 #pragma unroll 1
@@ -287,6 +299,21 @@ __device__ __noinline__ Fe<1> fe_inv(Fe<1> x) {
     t = fe_mul(fe_sqr(t), x);                    // 2^125 - 1
     return fe_mul(fe_sqr_n(t, 2), x);            // 2^127 - 3
 }
+// x^(2^125 - 1) = 1/sqrt(x) for squares (fields.py:108-122); any addition chain gives the same residue
+__device__ __noinline__ Fe<1> fe_invsqrt(Fe<1> x) {
+    Fe<1> x2 = fe_mul(x, fe_sqr(x));             // 2^2 - 1
+    Fe<1> x4 = fe_mul(x2, fe_sqr_n(x2, 2));      // 2^4 - 1
+    Fe<1> x5 = fe_mul(x, fe_sqr(x4));            // 2^5 - 1
+    Fe<1> acc = x5, cur = x5;
+#pragma unroll 1
+    for (int i = 0; i < 24; i++) {               // 2^(5(i+2)) - 1, as the reference's loop
+        cur = fe_sqr_n(cur, 5);
+        acc = fe_mul(cur, acc);
+    }
+    return acc;                                  // 2^125 - 1
+}
+FQ_DEV Fe<1> fe_half() { Fe<1> h; h.l[0] = h.l[1] = h.l[2] = h.l[3] = 0; h.l[4] = 1u << 22; return h; }   // 2^126 (fields.py:16)
+
 // conj(a) / (a0^2 + a1^2)                                                       fields.py:193-199
 template <int B> FQ_DEV Fe2<1> fe2_inv(const Fe2<B>& a) {
     Fe<1> n = fe_inv(fe_carry(fe_add(fe_sqr(a.re), fe_sqr(a.im))));

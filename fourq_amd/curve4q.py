@@ -30,6 +30,37 @@ def _prim_pt(op, *points):
     return codec.unpack_fp2s(default_engine().prim(op, row)[0])
 
 
+# ---- point encoding / decoding (curve4q.py:33-96) --------------------------------------------------
+_DECODE_EXC = {
+    1: (Exception, "Malformed point: reserved bit is not zero"),                      # curve4q.py:53, :62
+    2: (Exception, "Point not on curve"),                                             # curve4q.py:94
+    3: (AttributeError, "type object 'GFp' has no attribute 'two'"),                  # curve4q.py:77 (reference bug, kept)
+}
+
+
+def sign(X):                                                                          # curve4q.py:33-39
+    x0, x1 = X[0] % P127, X[1] % P127
+    return (x0 >> 126) if x0 != 0 else (x1 >> 126)
+
+
+def encode(X, Y):
+    """32-byte encoding of the affine point (X, Y) as a bytearray (curve4q.py:41-46)."""
+    row = codec.pack_point((X, Y)).reshape(1, 8)
+    return bytearray(default_engine().encode(row)[0].tobytes())
+
+
+def decode(B):
+    """Affine point of a 32-byte encoding; raises what the reference raises (curve4q.py:49-96).  Unlike the
+    reference the caller's buffer is left untouched (the reference clears the sign bit in place, :56)."""
+    if len(B) != 32:
+        raise Exception("Malformed point: length {} != 32".format(len(B)))
+    out, status = default_engine().decode(np.frombuffer(bytes(B), dtype=np.uint8).reshape(1, 32))
+    if status[0]:
+        exc, msg = _DECODE_EXC[int(status[0])]
+        raise exc(msg)
+    return codec.unpack_fp2s(out[0])
+
+
 # ---- membership and representations ------------------------------------------------------------
 def PointOnCurve(P):
     (X, Y) = P

@@ -157,6 +157,38 @@ class Engine:
         out[status != 0] = 0
         return out, status
 
+    # ---- point compression (32-byte wire format) -------------------------------------------------
+    def encode(self, points_affine):
+        """(n, 8) affine words -> (n, 32) uint8 encodings (curve4q.py:41-46)."""
+        p = _host(points_affine, 8)
+        out = np.empty((len(p), 32), dtype=np.uint8)
+        self._ck(self._lib.fourq_encode_batch(self._ctx, _ptr(p), _ptr(out), len(p)))
+        return out
+
+    def decode(self, encodings):
+        """(n, 32) uint8 -> ((n, 8) affine words, (n,) status) (curve4q.py:49-96; status = _lib.DECODE_*)."""
+        b = _host(encodings, 32, np.uint8)
+        out = np.empty((len(b), 8), dtype=np.uint64)
+        status = np.empty(len(b), dtype=np.uint8)
+        self._ck(self._lib.fourq_decode_batch(self._ctx, _ptr(b), _ptr(out), _ptr(status), len(b)))
+        return out, status
+
+    def dh_bytes(self, scalars, public_keys32, kind="endo", table=None):
+        """The protocol step of draft-ladd-cfrg-4q section "Diffie-Hellman": decode each 32-byte public key, DH_<kind> with
+        the scalar, encode the shared point.  Returns ((n, 32) uint8, status): 0 ok, 1/2 as DH_*, 16 + decode status."""
+        pts, dst = self.decode(public_keys32)
+        out, st = (self.dh_endo if kind == "endo" else self.dh_windowed)(scalars, pts, table)
+        status = np.where(dst != 0, 16 + dst, st).astype(np.uint8)
+        enc = self.encode(out)
+        enc[status != 0] = 0
+        return enc, status
+
+    def encode_dev(self, points_affine, out32, n):
+        self._ck(self._lib.fourq_encode_batch_dev(self._ctx, _ptr(points_affine), _ptr(out32), n))
+
+    def decode_dev(self, in32, out_affine, status, n):
+        self._ck(self._lib.fourq_decode_batch_dev(self._ctx, _ptr(in32), _ptr(out_affine), _ptr(status), n))
+
     # ---- device-pointer flavour (async on the engine's stream) ---------------------------------
     def mul_endo_dev(self, scalars, points_r1, out_r1, n):
         self._ck(self._lib.fourq_mul_endo_batch_dev(self._ctx, _ptr(scalars), _ptr(points_r1), _ptr(out_r1), n))

@@ -49,6 +49,19 @@ class GFp:
         return _fp("FP_INV", x)
 
     @staticmethod
+    def invsqrt(x):                                    # fields.py:110
+        return _fp("FP_INVSQRT", x)
+
+    @staticmethod
+    def toLittleEndian(x):                             # fields.py:125
+        return bytearray(int(x).to_bytes(16, "little"))
+
+    @staticmethod
+    def fromLittleEndian(x):                           # fields.py:129 (masks bit 127, in place like the reference)
+        x[15] &= 0x7F
+        return int.from_bytes(bytes(x), "little")
+
+    @staticmethod
     def select(c, x, y):                               # fields.py:60 -- host-side: no arithmetic involved
         return x if c == 1 else y
 

@@ -115,6 +115,18 @@ int fourq_dh_endo_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint6
 int fourq_dh_windowed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,
                                 uint64_t *out_affine, uint8_t *status, size_t n);
 
+/* ---- point compression: encode(X, Y) curve4q.py:41, decode(B) curve4q.py:49 -----------------------
+ * 32 bytes per point: y0 | y1 little-endian, sign(x) in the top bit of the last byte.  decode reports, per
+ * element, the exception the reference would raise; out_affine[i] is all zero unless status[i] == 0. */
+#define FOURQ_DECODE_OK 0
+#define FOURQ_DECODE_RESERVED_BIT 1        /* "Malformed point: reserved bit is not zero" (curve4q.py:53, :62) */
+#define FOURQ_DECODE_NOT_ON_CURVE 2        /* "Point not on curve" (curve4q.py:94) */
+#define FOURQ_DECODE_REF_ATTRIBUTE_ERROR 3 /* the reference's t == 0 branch (curve4q.py:76-77) raises AttributeError */
+int fourq_encode_batch(fourq_ctx *ctx, const uint64_t *points_affine, uint8_t *out32, size_t n);
+int fourq_decode_batch(fourq_ctx *ctx, const uint8_t *in32, uint64_t *out_affine, uint8_t *status, size_t n);
+int fourq_encode_batch_dev(fourq_ctx *ctx, const uint64_t *points_affine, uint8_t *out32, size_t n);
+int fourq_decode_batch_dev(fourq_ctx *ctx, const uint8_t *in32, uint64_t *out_affine, uint8_t *status, size_t n);
+
 /* ---- primitives (one reference function per op, batched) --------------------------------------
  * Used by the Python mirror of the reference's helper API (GFp.*, GFp2.*, DBL, ADD, phi, ...) and by
  * the parity tests to check every layer of the path on the GPU.  in/out are HOST pointers;
@@ -122,6 +134,7 @@ int fourq_dh_windowed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const u
 enum fourq_prim {
     /* GFp, fields.py:29-106: in = a[2] b[2] */
     FOURQ_FP_ADD = 0, FOURQ_FP_SUB = 1, FOURQ_FP_MUL = 2, FOURQ_FP_SQR = 3, FOURQ_FP_NEG = 4, FOURQ_FP_INV = 5,
+    FOURQ_FP_INVSQRT = 6,       /* fields.py:110 */
     /* GFp2, fields.py:156-199: in = a[4] b[4] */
     FOURQ_FP2_ADD = 16, FOURQ_FP2_SUB = 17, FOURQ_FP2_MUL = 18, FOURQ_FP2_SQR = 19, FOURQ_FP2_NEG = 20,
     FOURQ_FP2_CONJ = 21, FOURQ_FP2_INV = 22,

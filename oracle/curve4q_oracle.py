@@ -479,6 +479,52 @@ def encode(x, y):  # curve4q.py:41-46 ; 32 bytes: y0 | y1, sign bit of x in the 
     return out
 
 
+def decode(B):
+    """32 bytes -> affine (x, y), as the reference's decode (curve4q.py:49-96), exceptions included.
+
+    Differences of form only: the input is not modified (the reference clears the sign bit in the caller's
+    bytearray, curve4q.py:56) and any bytes-like object is accepted.  The branch at curve4q.py:76-77 refers to
+    a GFp.two that does not exist; the reference therefore raises AttributeError whenever t == 0 (e.g. for the
+    encoding of the neutral point), and so does this restatement, with the same message."""
+    B = bytearray(B)
+    if len(B) != 32:
+        raise Exception("Malformed point: length {} != 32".format(len(B)))
+    if B[15] & 0x80:
+        raise Exception("Malformed point: reserved bit is not zero")
+    s = B[31] >> 7
+    B[31] &= 0x7F
+    y0 = int.from_bytes(B[:16], "little") & P127        # fromLittleEndian masks bit 127 (fields.py:129-132)
+    y1 = int.from_bytes(B[16:], "little") & P127
+    if y0 >= P127 or y1 >= P127:
+        raise Exception("Malformed point: reserved bit is not zero")
+    y = (y0, y1)
+    y2 = f2_sqr(y)
+    u0, u1 = f2_sub(y2, F2_ONE)
+    v0, v1 = f2_add(f2_mul(d, y2), F2_ONE)
+    t0 = fp_add(fp_mul(u0, v0), fp_mul(u1, v1))
+    t1 = fp_sub(fp_mul(u1, v0), fp_mul(u0, v1))
+    t2 = fp_add(fp_sqr(v0), fp_sqr(v1))
+    t3 = fp_add(fp_sqr(t0), fp_sqr(t1))
+    t3 = fp_mul(fp_invsqrt(t3), t3)
+    t = fp_mul(2, fp_add(t0, t3))
+    if t == 0:
+        raise AttributeError("type object 'GFp' has no attribute 'two'")   # curve4q.py:77
+    a = fp_invsqrt(fp_mul(t, fp_mul(t2, fp_sqr(t2))))
+    b = fp_mul(fp_mul(a, t2), t)
+    x0 = fp_mul(b, GFp.half)
+    x1 = fp_mul(fp_mul(a, t2), t1)
+    if t != fp_mul(t2, fp_sqr(b)):
+        x0, x1 = x1, x0
+    x = (x0, x1)
+    if sign(x) != s:
+        x = f2_neg(x)
+    if not PointOnCurve((x, y)):
+        x = f2_conj(x)
+    if not PointOnCurve((x, y)):
+        raise Exception("Point not on curve")
+    return (x, y)
+
+
 def kat_scalars(count=1000):
     """The deterministic scalar sequence of the reference's test_mul (curve4q.py:552-559)."""
     s = [0x3AD457AB55456230, 0x3A8B3C2C6FD86E0C, 0x7E38F7C9CFBB9166, 0x0028FD6CBDA458F0]

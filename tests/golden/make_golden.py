@@ -15,6 +15,7 @@ Files written
   tables.json     table_windowed / table_endo for G and random points
   mul.json        MUL_windowed / MUL_endo raw R1 outputs (with/without table, edge scalars)
   dh.json         DH_windowed / DH_endo outputs and both rejection cases
+  wire.json       encode / decode round trips, arbitrary strings, malformed inputs
 """
 import json
 import os
@@ -309,6 +310,42 @@ def make_dh():
     return out
 
 
+# ----------------------------------------------------------------------------- wire.json
+def make_wire():
+    """encode / decode (curve4q.py:33-96): round trips, arbitrary strings, malformed inputs, and the
+    AttributeError the reference raises on its t == 0 branch (curve4q.py:76-77)."""
+    rng = random.Random(1007)
+    G = C.AffineToR1(C.Gx, C.Gy)
+    out = {"roundtrip": [], "strings": [], "malformed": []}
+    pts = [(C.Gx, C.Gy), (F.GFp2.neg(C.Gx), C.Gy)]
+    pts += [C.R1toAffine(C.MUL_endo(rng.getrandbits(256), G)) for _ in range(62)]
+    for Pt in pts:
+        enc = C.encode(Pt[0], Pt[1])
+        assert C.decode(bytearray(enc)) == Pt
+        out["roundtrip"].append([hx(Pt), bytes(enc).hex()])
+
+    def outcome(raw):
+        try:
+            return ["ok", hx(C.decode(bytearray(raw)))]
+        except Exception as exc:
+            return [type(exc).__name__, str(exc)]
+
+    strings = [bytes(C.encode(C.Ox, C.Oy)), bytes(31) + b"\x80", b"\x01" + bytes(15) + b"\x00" * 16,
+               bytes([0xFF] * 15 + [0x7F] + [0] * 16), bytes([0] * 16 + [0xFF] * 15 + [0x7F]), bytes([0xFF] * 15 + [0x7F] + [0xFF] * 16)]
+    for _ in range(250):
+        raw = bytearray(rng.getrandbits(256).to_bytes(32, "little"))
+        raw[15] &= 0x7F
+        strings.append(bytes(raw))
+    for raw in strings:
+        out["strings"].append([raw.hex()] + outcome(raw))
+    bad = [bytes(31), bytes(33), b"", bytes(15) + b"\x80" + bytes(16), bytes([0xFF] * 32)]
+    for raw in bad:
+        out["malformed"].append([raw.hex()] + outcome(raw))
+    out["_layout"] = {"roundtrip": "affine point, encode() hex", "strings": "32-byte hex, 'ok' + decode() | exception type + message",
+                      "malformed": "hex, exception type + message"}
+    return out
+
+
 if __name__ == "__main__":
     dump("kat.json", hx(make_kat()))
     dump("field.json", make_field())
@@ -317,3 +354,4 @@ if __name__ == "__main__":
     dump("tables.json", make_tables())
     dump("mul.json", make_mul())
     dump("dh.json", make_dh())
+    dump("wire.json", make_wire())

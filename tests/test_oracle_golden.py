@@ -209,3 +209,19 @@ def test_dh_vectors(golden):
             assert str(ei.value) == msg
     for a, b, ab in unhex(g["exchange"]):
         assert o.dh_exchange(a, b) == ab
+
+
+def test_wire_vectors(golden):
+    """encode / decode (curve4q.py:33-96) incl. the exceptions the reference raises, by type and message."""
+    w = golden("wire.json", raw=True)
+    for Pt, enc in w["roundtrip"]:
+        Pt = unhex(Pt)
+        assert bytes(o.encode(Pt[0], Pt[1])).hex() == enc and o.decode(bytes.fromhex(enc)) == Pt
+    for row in w["strings"] + w["malformed"]:
+        raw = bytes.fromhex(row[0])
+        if row[1] == "ok":
+            assert o.decode(raw) == unhex(row[2])
+        else:
+            with pytest.raises(Exception) as ei:
+                o.decode(raw)
+            assert (type(ei.value).__name__, str(ei.value)) == (row[1], row[2])
