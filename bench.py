@@ -7,7 +7,8 @@
 
 One step = one pass of the hot path over one batch: 2^16 variable-base MUL_endo(m_i, P_i) per GPU
 (random 256-bit scalars; P_i = projective N-torsion points, raw R1 outputs of fixed-base [k_i]G),
-inputs and outputs resident in HBM.  Ranks are independent (weak scaling, no data-path
+inputs and outputs resident in HBM.  `--workload cfg3|cfg4|cfg5` runs the other BASELINE.json
+configurations at their per-GPU sizes (the headline the driver records is the default, cfg2).  Ranks are independent (weak scaling, no data-path
 collective).  Rank 0 prints ONE JSON line.  Synthetic data; integer arithmetic (dtype "u32x5"
 limbs of GF(2^127-1), reported as "u64" words at the ABI).
 """
@@ -21,9 +22,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH = 1 << 16                      # BASELINE.json configs[1]
-BYTES_PER_OP = 32 + 160 + 160        # scalar + R1 in + R1 out
-MADS_PER_OP = 100_100                # v_mad_u64_u32 issued per variable-base MUL_endo by this implementation
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md
 VALU_MAD_PEAK = 1024 * 64 / 4.0 * 2.4e9    # measured: a wave64 v_mad_u64_u32 occupies a SIMD for 4 cycles (profiles/true_rates_r01.txt)
 
@@ -60,43 +58,64 @@ def host_cores():
 def _cpu_worker(args):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import curve4q_oracle as o
-    pairs, = args
+    kind, items, extra = args
+    G = (o.Gx, o.Gy)
     t0 = time.perf_counter()
-    outs = [o.MUL_endo(m, P) for m, P in pairs]
+    if kind == "mul_endo":
+        outs = [o.MUL_endo(m, P) for m, P in items]
+    elif kind == "mul_windowed_fixed":
+        outs = [o.MUL_windowed(m, None_r1(o), table=extra) for m in items]
+    elif kind == "dh_exchange":
+        outs = [o.DH_endo(a, o.DH_endo(b, G, table=extra)) for a, b in items]
+    else:  # mixed: (m, P or None)
+        outs = [o.MUL_endo(m, P) if P is not None else o.MUL_endo(m, None_r1(o), table=extra) for m, P in items]
     return time.perf_counter() - t0, outs
 
 
-def cpu_baseline(scalars, points, gpu_out, target_seconds=12.0):
-    """Times the pure-Python oracle (oracle/curve4q_oracle.py, kind "port") on the host cores over a
-    bounded sample of the SAME workload, and uses the sample as a parity gate on the GPU result."""
+def None_r1(o):
+    return o.AffineToR1(o.Gx, o.Gy)     # with a table the reference ignores the point (curve4q.py:209, :426)
+
+
+def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
+    """Times the pure-Python oracle (oracle/curve4q_oracle.py, kind "port") on the host cores over a bounded
+    sample of the SAME workload, and uses that sample as a parity gate on the GPU result (`expected`: the
+    GPU's outputs for the same items, as tuples)."""
     import multiprocessing as mp
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import curve4q_oracle as o
-    from fourq_amd import codec
     cores = host_cores()
-    ms, ps = codec.unpack_scalars(scalars[:4]), codec.unpack_points(points[:4])
     t0 = time.perf_counter()
-    for m, P in zip(ms, ps):
-        o.MUL_endo(m, P)
+    _cpu_worker((kind, items[:4], extra))
     per_op = (time.perf_counter() - t0) / 4
-    per_core = max(8, min(len(scalars) // cores, int(target_seconds / per_op)))
+    per_core = max(8, min(len(items) // cores, int(target_seconds / per_op)))
     total = per_core * cores
-    ms, ps = codec.unpack_scalars(scalars[:total]), codec.unpack_points(points[:total])
-    chunks = [([(ms[i], ps[i]) for i in range(c * per_core, (c + 1) * per_core)],) for c in range(cores)]
+    chunks = [(kind, items[c * per_core:(c + 1) * per_core], extra) for c in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
         results = pool.map(_cpu_worker, chunks)
     wall = time.perf_counter() - t0
     outs = [x for _, chunk in results for x in chunk]
-    want = codec.pack_points(outs, 5)
-    import numpy as np
-    if not np.array_equal(want, gpu_out[:total]):
-        raise SystemExit("PARITY FAILURE: GPU MUL_endo differs from the oracle on the cpu_baseline sample")
+    if outs != expected[:total]:
+        raise SystemExit("PARITY FAILURE: GPU result differs from the oracle on the cpu_baseline sample (%s)" % what)
     busy = max(t for t, _ in results)
     return {"value": round(total / busy, 1), "unit": "scalar-mults/s", "cores": cores, "kind": "port",
-            "sample": "%d of the batch's (scalar, point) pairs, MUL_endo via oracle/curve4q_oracle.py (pure Python big ints), "
-                      "%d per core on %d processes, %.1f s wall; outputs compared bit-exact with the GPU's" % (total, per_core, cores, wall),
+            "sample": "%d units of the timed batch, %s via oracle/curve4q_oracle.py (pure Python big ints), %d per core on %d "
+                      "processes, %.1f s wall; outputs compared bit-exact with the GPU's" % (total, what, per_core, cores, wall),
             "per_core": round(per_core / busy, 1)}
+
+
+# per-workload constants: algorithmic bytes per unit (SURVEY.md 8d) and v_mad_u64_u32 issued per unit by this
+# implementation (DESIGN.md section 5)
+WORKLOADS = {
+    "cfg2": dict(batch=1 << 16, bytes=32 + 160 + 160, mads=100_100, kernel="ladder_kernel<ENDO, FUSED>",
+                 text="BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
+                      "projective N-torsion points, raw R1 in/out resident in HBM"),
+    "cfg3": dict(batch=1 << 20, bytes=32 + 160, mads=164_000, kernel="ladder_kernel<WINDOWED, LDS>",
+                 text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
+    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=83_300 + 100_100 + 2 * 11_000, kernel="ladder_kernel<ENDO, LDS, DH> + prep/ladder<ENDO, PREBUILT, DH>",
+                 text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
+                      "(first half fixed-base with table_endo([392]G), second half variable-base); affine in/out"),
+    "cfg5": dict(batch=1 << 17, bytes=(192 + 352) // 2, mads=(83_300 + 100_100) // 2, kernel="ladder_kernel<ENDO, LDS> + ladder_kernel<ENDO, FUSED> over a device-side partition",
+                 text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo"),
+}
 
 
 def main():
@@ -104,7 +123,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH, help="elements per GPU per step (default: BASELINE config 2)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2", help="BASELINE.json configuration (default: the headline, cfg2)")
+    ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: the workload's BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -123,20 +143,50 @@ def main():
     torch.cuda.set_stream(stream)
     eng = Engine(local_rank, stream=stream.cuda_stream)
 
-    n = args.batch
-    # ---- synthetic workload, generated on the GPU: rank r uses seeds 20002+2r / 20003+2r
-    g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
+    wl = WORKLOADS[args.workload]
+    n = args.batch or wl["batch"]
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    # ---- synthetic workload, generated on the GPU: rank r uses seeds base+2r, base+1+2r
+    seed = {"cfg2": 20002, "cfg3": 30002, "cfg4": 40002, "cfg5": 50002}[args.workload] + 2 * rank
+    G_aff = (constants.Gx, constants.Gy)
+    g1 = codec.pack_point(G_aff + ((1, 0),) + G_aff)
     table_g = eng.table_endo(g1)
-    scalars_h = seeded_scalars(20002 + 2 * rank, n)
-    scalars = torch.from_numpy(scalars_h.view(np.int64)).to(dev)
-    k_dev = torch.from_numpy(seeded_scalars(20003 + 2 * rank, n).view(np.int64)).to(dev)
+    scalars_h = seeded_scalars(seed, n)
+    scalars = to_dev(scalars_h)
+    second_h = seeded_scalars(seed + 1, n)
+    second = to_dev(second_h)
     points = torch.empty((n, 20), dtype=torch.int64, device=dev)
-    eng.mul_endo_fixed_dev(k_dev, table_g, points, n)          # P_i = [k_i]G, raw R1 (projective, Z != 1)
+    eng.mul_endo_fixed_dev(second, table_g, points, n)          # P_i = [k_i]G, raw R1 (projective, Z != 1)
     out = torch.empty((n, 20), dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
+    extra_h = None
+    if args.workload == "cfg2":
+        def step():
+            eng.mul_endo_dev(scalars, points, out, n)
+    elif args.workload == "cfg3":
+        extra_h = eng.table_windowed(g1)
 
-    def step():
-        eng.mul_endo_dev(scalars, points, out, n)
+        def step():
+            eng.mul_windowed_fixed_dev(scalars, extra_h, out, n)
+    elif args.workload == "cfg4":
+        g392 = eng.mul_endo(codec.pack_scalars([392]), g1.reshape(1, 20))[0]      # curve4q.py:758
+        extra_h = eng.table_endo(g392)
+        g_aff = to_dev(np.repeat(codec.pack_point(G_aff).reshape(1, 8), n, axis=0))
+        mid = torch.empty((n, 8), dtype=torch.int64, device=dev)
+        out = torch.empty((n, 8), dtype=torch.int64, device=dev)
+        st1 = torch.empty(n, dtype=torch.uint8, device=dev)
+        st2 = torch.empty(n, dtype=torch.uint8, device=dev)
+
+        def step():
+            eng.dh_endo_dev(second, g_aff, extra_h, mid, st1, n)      # DH_endo(b, G, table)
+            eng.dh_endo_dev(scalars, mid, None, out, st2, n)          # DH_endo(a, .)
+    else:
+        extra_h = table_g
+        flags_h = (np.frombuffer(random.Random(seed + 7).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
+        flags = torch.from_numpy(flags_h).to(dev)
+
+        def step():
+            eng.mul_endo_mixed_dev(scalars, points, flags, extra_h, out, n)
+    torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -166,29 +216,43 @@ def main():
     gathered = gather_rows(out, n * world, dst=0) if world > 1 else out
     if rank == 0:
         assert gathered.shape[0] == n * world
-        out_h = out.cpu().numpy().view(np.uint64)
-        pts_h = points.cpu().numpy().view(np.uint64)
         total = n * world * args.steps
         value = total / elapsed
-        ach_gbs = BYTES_PER_OP * n / (kernel_ms * 1e-3) / 1e9
+        ach_gbs = wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9
+        mad_rate = wl["mads"] * n / (kernel_ms * 1e-3)
         line = {
             "metric": "FourQ scalar-mults/sec (batch, whole node)", "value": round(value, 1), "unit": "scalar-mults/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
-                                   "projective N-torsion points, raw R1 in/out resident in HBM",
-                       "batch_per_gpu": n, "parallelism": "independent shards x%d, no data-path collective" % world},
+            "config": {"workload": wl["text"], "batch_per_gpu": n, "parallelism": "independent shards x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic(),
-                         "kernel": "ladder_kernel<ENDO, variable base>", "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": BYTES_PER_OP * n,
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic() if args.workload == "cfg2" else None,
+                         "kernel": wl["kernel"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n,
                          "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
-            "valu_roofline": {"bound": "valu-int (v_mad_u64_u32 issue)", "achieved": round(MADS_PER_OP * n / (kernel_ms * 1e-3) / 1e12, 3),
-                              "peak": round(VALU_MAD_PEAK / 1e12, 3), "unit": "Tmad/s",
-                              "frac": round(MADS_PER_OP * n / (kernel_ms * 1e-3) / VALU_MAD_PEAK, 4)},
+            "valu_roofline": {"bound": "valu-int (v_mad_u64_u32, 4 cycles per wave64 per SIMD)", "achieved": round(mad_rate / 1e12, 3),
+                              "peak": round(VALU_MAD_PEAK / 1e12, 3), "unit": "Tmad/s", "frac": round(mad_rate / VALU_MAD_PEAK, 4)},
         }
+        if args.workload == "cfg4":
+            line["config"]["note"] = "one unit = one exchange = two DH_core evaluations"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scalars_h, pts_h, out_h)
+            ms = codec.unpack_scalars(scalars_h)
+            out_h = out.cpu().numpy().view(np.uint64)
+            expected = codec.unpack_points(out_h)
+            if args.workload == "cfg2":
+                pts = codec.unpack_points(points.cpu().numpy().view(np.uint64))
+                line["cpu_baseline"] = cpu_baseline("mul_endo", list(zip(ms, pts)), None, expected, "MUL_endo(m, P)")
+            elif args.workload == "cfg3":
+                line["cpu_baseline"] = cpu_baseline("mul_windowed_fixed", ms, codec.unpack_table(extra_h), expected, "MUL_windowed(m, G, table)")
+            elif args.workload == "cfg4":
+                if bool(st1.any()) or bool(st2.any()):
+                    raise SystemExit("cfg4: unexpected DH failure status")
+                bs = codec.unpack_scalars(second_h)
+                line["cpu_baseline"] = cpu_baseline("dh_exchange", list(zip(ms, bs)), codec.unpack_table(extra_h), expected,
+                                                    "DH_endo(a, DH_endo(b, G, table))")
+            else:
+                pts = codec.unpack_points(points.cpu().numpy().view(np.uint64))
+                items = [(m, P if f else None) for m, P, f in zip(ms, pts, flags_h)]
+                line["cpu_baseline"] = cpu_baseline("mixed", items, codec.unpack_table(extra_h), expected, "50/50 fixed/variable MUL_endo")
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

@@ -48,6 +48,8 @@ struct LadderArgs {
     uint8_t* status;       // DH only
     const u32* index;      // optional: element ids to process (mixed batches); NULL = identity
     u32 base;              // first position of this launch (chunked large batches)
+    const u32* n_dev;      // optional: element count read on the device (mixed batches: no host round trip)
+    u32 rev;               // non-zero: ids are index[rev - 1 - pos] (the variable-base half of a partition, filled from the end)
     const u32* table;      // fixed base: 8 x 40 limbs (global), staged to LDS
     u32* scratch;          // variable base: SLOT_U32 per resident lane
     u32 n;
@@ -180,14 +182,15 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             lds_table[(i / R2_LIMBS) * LDS_ENTRY_U32 + (i % R2_LIMBS)] = a.table[i];
         __syncthreads();
     }
+    const u32 n = a.n_dev ? *a.n_dev : a.n;
     const u32 lane_slot = blockIdx.x * BLOCK + threadIdx.x;
     const u32 lanes = gridDim.x * BLOCK;
-    const u32 n_round = (a.n + BLOCK - 1) / BLOCK * BLOCK;
+    const u32 n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
 #pragma unroll 1
     for (u32 it = lane_slot; it < n_round; it += lanes) {
-        const bool live = it < a.n;
-        const u32 pos = live ? it : a.n - 1;              // idle tail lanes redo the last element, store nothing
-        const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
+        const bool live = it < n;
+        const u32 pos = live ? it : n - 1;                // idle tail lanes redo the last element, store nothing
+        const u32 id = a.index ? a.index[a.rev ? a.rev - 1 - pos : a.base + pos] : a.base + pos;
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
         u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * SLOT_U32;
@@ -413,6 +416,10 @@ struct fourq_ctx {
     u32* table_limbs = nullptr;    // 8 x 40
     u64* table_packed = nullptr;   // 128 words
     u32* part_counters = nullptr;  // 2
+    u32* part_index = nullptr;     // element ids of a mixed batch, partitioned by flag
+    size_t part_capacity = 0;
+    hipStream_t aux_stream = nullptr;   // the variable-base half of a mixed batch runs beside the fixed-base half
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* stage = nullptr;         // staging for the host-pointer API
     size_t stage_bytes = 0;
     char err[256] = { 0 };
@@ -611,6 +618,9 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_counters, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
     } while (0);
     if (rc) { fourq_ctx_destroy(c); return rc; }
     *out = c;
@@ -625,6 +635,10 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->table_limbs) (void)hipFree(c->table_limbs);
     if (c->table_packed) (void)hipFree(c->table_packed);
     if (c->part_counters) (void)hipFree(c->part_counters);
+    if (c->part_index) (void)hipFree(c->part_index);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stage) (void)hipFree(c->stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -708,23 +722,37 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     if (!c || !s || !p || !flags || !table || !o || n > 0xffffffffu) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    int rc = ensure_stage(c, 0);   // keep the staging buffer for the host wrapper; the index list has its own allocation
+    if (n > c->part_capacity) {                       // grows only: steady-state calls allocate nothing
+        if (c->part_index) { HIP_TRY(c, hipFree(c->part_index)); c->part_index = nullptr; c->part_capacity = 0; }
+        HIP_TRY(c, hipMalloc(&c->part_index, n * sizeof(u32)));
+        c->part_capacity = n;
+    }
+    int rc = stage_table(c, table);
     if (rc) return rc;
-    u32* idx = nullptr;
-    HIP_TRY(c, hipMalloc(&idx, n * sizeof(u32)));
-    u32 counts[2] = { 0, 0 };
-    rc = FOURQ_OK;
-    do {
-        if (hipMemsetAsync(c->part_counters, 0, 2 * sizeof(u32), c->stream) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
-        hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, flags, (u32)n, idx, c->part_counters);
-        if (hipMemcpyAsync(counts, c->part_counters, sizeof counts, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
-        if (counts[0]) rc = mul_dev(c, ENDO, s, nullptr, table, o, idx, counts[0]);
-        if (!rc && counts[1]) rc = mul_dev(c, ENDO, s, p, nullptr, o, idx + (n - counts[1]), counts[1]);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = rc ? rc : FOURQ_ERR_HIP;
-    } while (0);
-    (void)hipFree(idx);
-    return rc;
+    HIP_TRY(c, hipMemsetAsync(c->part_counters, 0, 2 * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, flags, (u32)n, c->part_index, c->part_counters);
+    HIP_TRY(c, hipGetLastError());
+    // fixed-base ids fill part_index from the front, variable-base ids from the back; both counts stay on the device.
+    // The two halves are independent: the variable-base half runs on the auxiliary stream beside the fixed-base half.
+    LadderArgs a = {};
+    a.scalars = s; a.points = p; a.out = o; a.index = c->part_index; a.n = (u32)n;
+    a.scratch = c->scratch; a.table = c->table_limbs;
+    size_t blocks = (n + BLOCK - 1) / BLOCK;
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    LadderArgs av = a;
+    av.n_dev = c->part_counters + 1; av.rev = (u32)n;
+    unsigned gv = (unsigned)(blocks < c->lanes / BLOCK ? blocks : c->lanes / BLOCK);
+    hipLaunchKernelGGL((ladder_kernel<ENDO, FUSED, false>), dim3(gv), dim3(BLOCK), 0, c->aux_stream, av);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+    LadderArgs af = a;
+    af.n_dev = c->part_counters;
+    unsigned gf = (unsigned)(blocks < c->lanes_w4 / BLOCK ? blocks : c->lanes_w4 / BLOCK);
+    hipLaunchKernelGGL((ladder_kernel<ENDO, LDS, false>), dim3(gf), dim3(BLOCK), 0, c->stream, af);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return FOURQ_OK;
 }
 FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint8_t* flags,
                                       const uint64_t* table, uint64_t* o, size_t n) {
@@ -738,6 +766,11 @@ FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uin
     HIP_TRY(c, hipMemcpyAsync(base, s, sb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(base + sb, p, pb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(base + sb + pb + ob, flags, n, hipMemcpyHostToDevice, c->stream));
+    if (n > c->part_capacity) {                       // allocate the index list before staging: growing it must not free `stage`
+        if (c->part_index) { HIP_TRY(c, hipFree(c->part_index)); c->part_index = nullptr; c->part_capacity = 0; }
+        HIP_TRY(c, hipMalloc(&c->part_index, n * sizeof(u32)));
+        c->part_capacity = n;
+    }
     rc = fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)base, (const uint64_t*)(base + sb), (const uint8_t*)(base + sb + pb + ob),
                                         table, (uint64_t*)(base + sb + pb), n);
     if (rc) return rc;
