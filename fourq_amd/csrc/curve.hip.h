@@ -94,10 +94,10 @@ FQ_DEV R1 dbl(const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
     Fe2<4> E = fe2_sub(fe2_sqr(fe2_add(X, Y)), D);
     Fe2<3> F = fe2_sub(B, A);
     Fe2<6> G = fe2_sub(C, F);
-    R1 r;
-    r.X = fe2_mul(G, E);
+    R1 r;                      // operand roles chosen so that 8*G (second operand) and -F.im (first) are shared
+    r.X = fe2_mul(E, G);
+    r.Z = fe2_mul(F, G);
     r.Y = fe2_mul(F, D);
-    r.Z = fe2_mul(G, F);
     r.Ta = E;
     r.Tb = D;
     return r;
@@ -347,10 +347,10 @@ template <typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_m
     Fe2<3> F = fe2_sub(D, C);
     Fe2<2> G = fe2_add(D, C);
     Fe2<2> H = fe2_add(B, A);
-    R1 r;
+    R1 r;                      // 8*F shared by X and Z, -G.im shared by Z and Y
     r.X = fe2_mul(E, F);
+    r.Z = fe2_mul(G, F);
     r.Y = fe2_mul(G, H);
-    r.Z = fe2_mul(F, G);
     r.Ta = widen<4>(E);
     r.Tb = H;
     return r;

@@ -29,6 +29,9 @@ using namespace fq;
 namespace {
 
 constexpr int BLOCK = 256;
+#ifndef FQ_FUSED_WAVES
+#define FQ_FUSED_WAVES 1
+#endif
 constexpr int SLOT_U32 = 464;          // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
 constexpr int SLOT_P = 384, SLOT_Q = 424;
 constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
 
 // ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
 template <int ALGO, int SRC, bool DH>
-__global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
+__global__ __launch_bounds__(BLOCK, SRC == FUSED ? FQ_FUSED_WAVES : 4) void ladder_kernel(LadderArgs a) {
     __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : 4];
     if (SRC == LDS) {
         for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
