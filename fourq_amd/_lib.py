@@ -85,8 +85,13 @@ def load():
         except ImportError:
             pass
     if not os.path.exists(LIB_PATH):
-        raise FourQError(
-            "libfourq_amd.so is not built (%s). Run `python -m fourq_amd.build`; there is no CPU fallback." % LIB_PATH)
+        # a fresh checkout: build in-tree once (hipcc cross-compiles, ~1 minute); never a CPU substitute
+        try:
+            from .build import build_library
+            build_library()
+        except Exception as exc:
+            raise FourQError("libfourq_amd.so is not built (%s) and building it failed: %s. "
+                             "Run `python -m fourq_amd.build`; there is no CPU fallback." % (LIB_PATH, exc))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)   # AttributeError here = header / library mismatch

@@ -75,7 +75,6 @@ FQ_DEV void load_xyz(const u32* src, Fe2<1>& X, Fe2<1>& Y, Fe2<1>& Z) {
         for (int i = 0; i < 5; i++) { f[k]->re.l[i] = src[10 * k + i]; f[k]->im.l[i] = src[10 * k + 5 + i]; }
     }
 }
-FQ_DEV R3 r3_tight(const R3& p) { return p; }
 
 // T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                       curve4q.py:179-185
 FQ_DEV void build_table_windowed(const R1& P, u32* tbl) {

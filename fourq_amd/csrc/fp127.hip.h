@@ -253,7 +253,8 @@ template <int A, int B> FQ_DEV bool fe_equal(const Fe<A>& a, const Fe<B>& b) {
     return alo == blo && ahi == bhi;
 }
 template <int A, int B> FQ_DEV bool fe2_equal(const Fe2<A>& a, const Fe2<B>& b) {
-    return fe_equal(a.re, b.re) & fe_equal(a.im, b.im);
+    const bool re_eq = fe_equal(a.re, b.re), im_eq = fe_equal(a.im, b.im);   // both evaluated: no branch
+    return re_eq && im_eq;
 }
 
 // x if mask == ~0 else y (mask must be 0 or ~0): the branch-free GFp.select of fields.py:59-64
