@@ -194,3 +194,35 @@ def test_prep_plus_ladder_route_boundaries(n, monkeypatch):
         assert np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
         k = 20000
         assert np.array_equal(eng.mul_windowed(s, pts)[-k:], oc.mul(oc.WINDOWED, s[-k:], pts[-k:]))
+
+
+def test_special_base_points(eng, golden):
+    """Bases the formulas must still follow the reference on: the neutral point, -G, a point of order dividing 392
+    (MUL_* give 'wrong' answers off the N-torsion, curve4q.py docstring of the draft; parity is with the reference's)."""
+    from conftest import unhex
+    P392 = unhex(golden("kat.json", raw=True)["P392"])
+    bases = [o.AffineToR1(o.Ox, o.Oy), o.AffineToR1(o.f2_neg(o.Gx), o.Gy), o.AffineToR1(*P392),
+             (o.Gx, o.Gy, (1, 0), (0, 0), (0, 0)), ((0, 0), (0, 0), (0, 0), (0, 0), (0, 0))]
+    rng = random.Random(321)
+    ms = [0, 1, 2, 391, 392, o.N, (1 << 256) - 1] + [rng.getrandbits(256) for _ in range(5)]
+    rows = [(m, P) for P in bases for m in ms]
+    s = codec.pack_scalars([m for m, _ in rows])
+    p = codec.pack_points([P for _, P in rows], 5)
+    assert codec.unpack_points(eng.mul_endo(s, p)) == [o.MUL_endo(m, P) for m, P in rows]
+    assert codec.unpack_points(eng.mul_windowed(s, p)) == [o.MUL_windowed(m, P) for m, P in rows]
+
+
+def test_two_engines_and_reuse_after_error():
+    """Contexts are independent; an invalid call leaves a context usable."""
+    from fourq_amd import Engine, FourQError
+    s, g = seeded_scalars(5, 300), codec.pack_point(G1)
+    with Engine(0) as e1, Engine(0) as e2:
+        t1, t2 = e1.table_endo(g), e2.table_windowed(g)
+        a = e1.mul_endo_fixed(s, t1)
+        b = e2.mul_windowed_fixed(s, t2)
+        with pytest.raises(ValueError):
+            e1.mul_endo(s, np.zeros((7, 20), dtype=np.uint64))
+        with pytest.raises(FourQError):
+            e1.prim(999, np.zeros((1, 4), dtype=np.uint64))
+        assert np.array_equal(e1.mul_endo_fixed(s, t1), a) and np.array_equal(e2.mul_windowed_fixed(s, t2), b)
+        assert np.array_equal(a, oc.mul(oc.ENDO, s, None, t1)) and np.array_equal(b, oc.mul(oc.WINDOWED, s, None, t2))
