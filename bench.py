@@ -110,9 +110,10 @@ WORKLOADS = {
                       "projective N-torsion points, raw R1 in/out resident in HBM"),
     "cfg3": dict(batch=1 << 20, bytes=32 + 160, mads=164_000, kernel="ladder_kernel<WINDOWED, LDS>",
                  text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
-    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=83_300 + 100_100 + 2 * 11_000, kernel="ladder_kernel<ENDO, LDS, DH> + prep/ladder<ENDO, PREBUILT, DH>",
+    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=42_000 + 100_100 + 11_000, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH>",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
-                      "(first half fixed-base with table_endo([392]G), second half variable-base); affine in/out"),
+                      "(first half fixed-base through the 80-point comb of [392]G, same affine outputs as with table_endo([392]G); "
+                      "second half variable-base); affine in/out"),
     "cfg5": dict(batch=1 << 17, bytes=(192 + 352) // 2, mads=(83_300 + 100_100) // 2, kernel="ladder_kernel<ENDO, LDS> + ladder_kernel<ENDO, FUSED> over a device-side partition",
                  text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo"),
 }
@@ -176,8 +177,10 @@ def main():
         st1 = torch.empty(n, dtype=torch.uint8, device=dev)
         st2 = torch.empty(n, dtype=torch.uint8, device=dev)
 
+        comb_h = eng.comb_table(g392)                                     # 80-point comb of [392]G (draft :725-729)
+
         def step():
-            eng.dh_endo_dev(second, g_aff, extra_h, mid, st1, n)      # DH_endo(b, G, table)
+            eng.comb_mul_dev(second, comb_h, mid, st1, n)             # == DH_endo(b, G, table_endo([392]G)), affine
             eng.dh_endo_dev(scalars, mid, None, out, st2, n)          # DH_endo(a, .)
     else:
         extra_h = table_g

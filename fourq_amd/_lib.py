@@ -44,6 +44,9 @@ PROTOTYPES = {
     "fourq_dh_windowed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_endo_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_windowed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_comb_table": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fourq_comb_mul_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_comb_mul_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_encode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_decode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_encode_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),

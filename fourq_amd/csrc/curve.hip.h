@@ -355,6 +355,44 @@ template <typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_m
     r.Tb = H;
     return r;
 }
+// Q + (+-A) for a precomputed AFFINE point A = (x+y, y-x, 2d*x*y) read from `entry` (three coordinates of
+// COORD_U32 dwords): ADD_core with the table point's 2Z = 2, i.e. D = 2*Z1 costs no multiplication.  Used by
+// the fixed-base comb, not by the reference-shaped MUL_* paths.
+template <typename P> FQ_DEV R1 add_affine_table(const R1& q, const P* entry, u32 neg_mask) {
+    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
+    Fe2<1> T = fe2_mul(q.Ta, q.Tb);
+    Fe2<2> N1 = fe2_add(q.X, q.Y);
+    Fe2<3> D1 = fe2_sub(q.Y, q.X);
+    Fe2<1> A = fe2_mul(D1, load_fe2_limbs(entry + off_d));
+    Fe2<1> B = fe2_mul(N1, load_fe2_limbs(entry + off_n));
+    Fe2<1> C = fe2_mul(fe2_cneg(load_fe2_limbs(entry + 2 * COORD_U32), neg_mask), T);
+    Fe2<2> D = fe2_dbl(q.Z);
+    Fe2<3> E = fe2_sub(B, A);
+    Fe2<4> F = fe2_sub(D, C);
+    Fe2<3> G = fe2_add(D, C);
+    Fe2<2> H = fe2_add(B, A);
+    R1 r;
+    r.X = fe2_mul(E, F);
+    r.Z = fe2_mul(G, F);
+    r.Y = fe2_mul(G, H);
+    r.Ta = widen<4>(E);
+    r.Tb = H;
+    return r;
+}
+// the comb's starting point: +-A as an R1 point (Z = 1)
+template <typename P> FQ_DEV R1 affine_table_start(const P* entry, u32 neg_mask) {
+    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
+    Fe2<1> N = load_fe2_limbs(entry + off_n), D = load_fe2_limbs(entry + off_d);     // x+y, y-x of +-A
+    // x = (N - D)/2, y = (N + D)/2: keep the factor 2 projectively: (X, Y, Z) = (N - D, N + D, 2)
+    R1 r;
+    r.X = fe2_carry(fe2_sub(N, D));
+    r.Y = fe2_carry(fe2_add(N, D));
+    r.Z = fe2_carry(fe2_dbl(fe2_one()));
+    r.Ta = widen<4>(r.X);                                   // Ta*Tb must equal X*Y/Z = (N-D)(N+D)/2
+    r.Tb = widen<2>(fe2_mul(r.Y, fe2_half_const()));        // Tb = (N+D)/2
+    return r;
+}
+
 // R2toR4(selectpt(s, T, nT)): the ladder's starting point (curve4q.py:229, :437)
 template <typename P> FQ_DEV Proj<1, 1, 1> start_table(const P* entry, u32 neg_mask) {
     const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;

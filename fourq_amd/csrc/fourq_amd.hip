@@ -269,6 +269,85 @@ __global__ void partition_kernel(const uint8_t* flags, u32 n, u32* idx, u32* cou
     else idx[n - 1 - atomicAdd(&counters[1], 1u)] = i;
 }
 
+// ---- fixed-base comb -------------------------------------------------------------
+constexpr int COMB_POINTS = COMB_V << (COMB_W - 1);          // 80
+constexpr int COMB_ENTRY_U32 = 3 * COORD_U32;                 // (x+y, y-x, 2dxy)
+constexpr int COMB_LDS_U32 = COMB_ENTRY_U32 + 4;              // padded stride in LDS
+
+// One lane per table entry: P[j][u] = [2^(e j) (1 + u0 2^d + u1 2^2d + u2 2^3d + u3 2^4d)] B by the ordinary
+// variable-base MUL_endo, normalised to affine and stored as (x+y, y-x, 2d x y), 12 packed words.
+__global__ __launch_bounds__(128) void comb_table_kernel(const u64* p_r1, u32* scratch, u64* comb) {
+    const u32 t = threadIdx.x;
+    if (t >= COMB_POINTS) return;
+    const u32 j = t >> (COMB_W - 1), u = t & ((1u << (COMB_W - 1)) - 1);
+    u64 m[4] = { 0, 0, 0, 0 };
+    auto set_bit = [&](int bit) { m[bit >> 6] |= 1ull << (bit & 63); };
+    set_bit(COMB_E * j);
+    for (int r = 0; r < COMB_W - 1; r++) if ((u >> r) & 1) set_bit(COMB_E * j + (r + 1) * COMB_D);
+    R1 P = load_r1(p_r1);
+    u32* slot = scratch + (size_t)t * SLOT_U32;
+    build_table_endo(P, slot);
+    u64 v[4];
+    decompose(m, v);
+    R1 Q = ladder_endo(recode(v), slot, R2_LIMBS);
+    Fe2<1> x, y;
+    r1_to_affine(Q, x, y);
+    u64* dst = comb + 12 * (size_t)t;
+    store_fe2(dst, fe2_add(x, y));
+    store_fe2(dst + 4, fe2_sub(y, x));
+    store_fe2(dst + 8, fe2_mul(fe2_mul(x, y), fe2_two_d()));
+}
+__global__ void comb_unpack_kernel(const u64* packed, u32* limbs) {
+    int k = threadIdx.x;
+    if (k >= COMB_POINTS) return;
+    for (int c = 0; c < 3; c++) store_fe2_limbs(limbs + k * COMB_ENTRY_U32 + c * COORD_U32, load_fe2(packed + 12 * k + 4 * c));
+}
+// [m]B, affine, from the comb: 9 doublings + 49 mixed additions per element
+__global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
+    __shared__ __attribute__((aligned(16))) u32 lds[COMB_POINTS * COMB_LDS_U32];
+    for (int i = threadIdx.x; i < COMB_POINTS * COMB_ENTRY_U32; i += BLOCK)
+        lds[(i / COMB_ENTRY_U32) * COMB_LDS_U32 + (i % COMB_ENTRY_U32)] = comb_limbs[i];
+    __syncthreads();
+    const u32 lanes = gridDim.x * BLOCK;
+    const u32 n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
+#pragma unroll 1
+    for (u32 it = blockIdx.x * BLOCK + threadIdx.x; it < n_round; it += lanes) {
+        const bool live = it < n;
+        const u32 id = live ? it : n - 1;
+        u64 m[4];
+        load_scalar(scalars + 4 * (size_t)id, m);
+        CombDigits c = comb_recode(m);
+        R1 Q;
+#pragma unroll 1
+        for (int i = COMB_E - 1; i >= 0; i--) {
+#pragma unroll 1
+            for (int j = 0; j < COMB_V; j++) {
+                const int col = COMB_E * j + i;
+                const u32* entry = lds + ((j << (COMB_W - 1)) + comb_index(c, col)) * COMB_LDS_U32;
+                const u32 neg = comb_neg_mask(c, col);
+                if (i == COMB_E - 1 && j == 0) { Q = affine_table_start(entry, neg); continue; }
+                if (j == 0) Q = dbl(Q.X, Q.Y, Q.Z);
+                Q = add_affine_table(Q, entry, neg);
+            }
+        }
+        Fe2<1> ax, ay;
+        r1_to_affine(Q, ax, ay);
+        ax = fe2_carry(fe2_cneg(ax, c.negate));               // even scalar: [k]B = -[N - k]B, -(x, y) = (-x, y)
+        u64 o[8];
+        store_fe2(o, ax); store_fe2(o + 4, ay);
+        const bool neutral = (o[0] | o[1] | o[2] | o[3] | o[5] | o[6] | o[7]) == 0 && o[4] == 1;
+        if (live) {
+            uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)id);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u64 lo = neutral ? 0 : o[2 * k], hi = neutral ? 0 : o[2 * k + 1];
+                dst[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+            }
+            status[id] = neutral ? FOURQ_DH_NEUTRAL : FOURQ_DH_OK;
+        }
+    }
+}
+
 // ---- point compression ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void encode_kernel(const u64* affine, u64* out, u32 n) {
     u32 i = blockIdx.x * BLOCK + threadIdx.x;
@@ -417,6 +496,8 @@ struct fourq_ctx {
     u32* scratch = nullptr;        // max(lanes, lanes_w4) x SLOT_U32
     u32* table_limbs = nullptr;    // 8 x 40
     u64* table_packed = nullptr;   // 128 words
+    u32* comb_limbs = nullptr;     // 80 x 36 working limbs of the staged comb table
+    u64* comb_packed = nullptr;    // 80 x 12 words
     u32* part_counters = nullptr;  // 2
     u32* part_index = nullptr;     // element ids of a mixed batch, partitioned by flag
     size_t part_capacity = 0;
@@ -620,6 +701,8 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_counters, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->comb_limbs, COMB_POINTS * COMB_ENTRY_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->comb_packed, FOURQ_COMB_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
         if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
         if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
@@ -637,6 +720,8 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->table_limbs) (void)hipFree(c->table_limbs);
     if (c->table_packed) (void)hipFree(c->table_packed);
     if (c->part_counters) (void)hipFree(c->part_counters);
+    if (c->comb_limbs) (void)hipFree(c->comb_limbs);
+    if (c->comb_packed) (void)hipFree(c->comb_packed);
     if (c->part_index) (void)hipFree(c->part_index);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -792,6 +877,47 @@ FQ_API int fourq_dh_endo_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64
 }
 FQ_API int fourq_dh_windowed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
     return dh_dev(c, WINDOWED, s, p, t, o, st, n);
+}
+
+FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) {
+    if (!c || !p_r1 || !comb) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    int rc = ensure_stage(c, 160);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->stage, p_r1, 160, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(comb_table_kernel, dim3(1), dim3(128), 0, c->stream, (const u64*)c->stage, c->scratch, c->comb_packed);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(comb, c->comb_packed, FOURQ_COMB_WORDS * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
+}
+FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
+    if (!c || !scalars || !comb || !out || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(c->comb_packed, comb, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(comb_unpack_kernel, dim3(1), dim3(128), 0, c->stream, c->comb_packed, c->comb_limbs);
+    HIP_TRY(c, hipGetLastError());
+    size_t blocks = (n + BLOCK - 1) / BLOCK, blocks_max = c->lanes_w4 / BLOCK;
+    hipLaunchKernelGGL(comb_kernel, dim3((unsigned)(blocks < blocks_max ? blocks : blocks_max)), dim3(BLOCK), 0, c->stream, scalars, c->comb_limbs, out, status, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
+    if (!c || !scalars || !comb || !out || !status) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    size_t sb = n * 32, ob = n * 64;
+    int rc = ensure_stage(c, sb + ob + n + 16);
+    if (rc) return rc;
+    char* base = (char*)c->stage;
+    HIP_TRY(c, hipMemcpyAsync(base, scalars, sb, hipMemcpyHostToDevice, c->stream));
+    rc = fourq_comb_mul_batch_dev(c, (const uint64_t*)base, comb, (uint64_t*)(base + sb), (uint8_t*)(base + sb + ob), n);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, base + sb, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(status, base + sb + ob, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FOURQ_OK;
 }
 
 FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {

@@ -315,6 +315,8 @@ __device__ __noinline__ Fe<1> fe_invsqrt(Fe<1> x) {
 }
 FQ_DEV Fe<1> fe_half() { Fe<1> h; h.l[0] = h.l[1] = h.l[2] = h.l[3] = 0; h.l[4] = 1u << 22; return h; }   // 2^126 (fields.py:16)
 
+FQ_DEV Fe2<1> fe2_half_const() { Fe2<1> h; h.re = fe_half(); for (int i = 0; i < 5; i++) h.im.l[i] = 0; return h; }   // 2^126 = 1/2
+
 // conj(a) / (a0^2 + a1^2)                                                       fields.py:193-199
 template <int B> FQ_DEV Fe2<1> fe2_inv(const Fe2<B>& a) {
     Fe<1> n = fe_inv(fe_carry(fe_add(fe_sqr(a.re), fe_sqr(a.im))));

@@ -158,4 +158,66 @@ FQ_DEV u32 win_top_code(const WinScalar& w) {        // digit 62 = (r >> 252) | 
     return (1u << 3) | (((d - 1) >> 1) & 7);
 }
 
+// ---- fixed-base comb: mLSB-set recoding, w = 5, v = 5, e = 10, d = 50 -----------------
+// (Faz-Hernandez, Longa, Sanchez: the method the draft points to for multiplications by the generator,
+// draft-ladd-cfrg-4q.md:725-729.)  For odd k < 2^250:  k = sum_{i<250} b_i 2^i with b_i in {+-1} for i < d and
+// b_i in {0, b_{i mod d}} above.  Column i (0 <= i < d) carries the sign b_i and the 4-bit index
+// (|b_{4d+i}| |b_{3d+i}| |b_{2d+i}| |b_{d+i}|); stored as five 50-bit planes.
+constexpr int COMB_W = 5, COMB_V = 5, COMB_E = 10, COMB_D = 50;
+struct CombDigits {
+    u64 plane[COMB_W];   // plane[0] bit i: b_i == +1 ; plane[r] bit i: |b_{r d + i}|
+    u32 negate;          // ~0 when the scalar was replaced by N - k (even k): the result is negated
+};
+FQ_DEV CombDigits comb_recode(const u64 m[4]) {
+    WinScalar red = win_reduce(m);                    // k mod N made odd by ADDING N when even (curve4q.py:217-219) ...
+    // ... the comb wants odd k < N instead: undo the +N and use N - k, negating the result
+    u64 k[4] = { red.r[0], red.r[1], red.r[2], red.r[3] };
+    // win_reduce returns r = (m mod N) if that is odd, else (m mod N) + N.  Recover parity of (m mod N):
+    // (m mod N) + N >= N, and an odd (m mod N) is < N, so "k >= N" identifies the even case exactly.
+    u64 n[4] = { ORDER_N[0], ORDER_N[1], ORDER_N[2], ORDER_N[3] };
+    const bool was_even = ge256(k, n);
+    // even case: k_red = k - N (even), want N - k_red = 2N - k
+    u64 twoN[4], alt[4];
+    twoN[0] = n[0] << 1; twoN[1] = (n[1] << 1) | (n[0] >> 63); twoN[2] = (n[2] << 1) | (n[1] >> 63); twoN[3] = (n[3] << 1) | (n[2] >> 63);
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 d1 = twoN[i] - k[i], b1 = twoN[i] < k[i];
+        u64 d2 = d1 - borrow, b2 = d1 < borrow;
+        alt[i] = d2; borrow = b1 | b2;
+    }
+    CombDigits c;
+    c.negate = was_even ? ~0u : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[i] = was_even ? alt[i] : k[i];        // odd, in [1, N]
+    const u64 mask_d = (1ull << COMB_D) - 1;
+    const u64 sign = ((k[0] >> 1) & (mask_d >> 1)) | (1ull << (COMB_D - 1));     // b_i = +1  <=>  bit set
+    c.plane[0] = sign;
+    // carry word c = k >> d (200 bits)
+    u64 c0 = (k[0] >> COMB_D) | (k[1] << (64 - COMB_D)), c1 = (k[1] >> COMB_D) | (k[2] << (64 - COMB_D));
+    u64 c2 = (k[2] >> COMB_D) | (k[3] << (64 - COMB_D)), c3 = k[3] >> COMB_D;
+#pragma unroll 1
+    for (int r = 1; r < COMB_W; r++) {
+        u64 pl = 0;
+#pragma unroll 1
+        for (int i = 0; i < COMB_D; i++) {
+            u64 bit = c0 & 1;
+            pl |= bit << i;
+            u64 inc = bit & ~(sign >> i) & 1;          // b = -1  ->  c = (c >> 1) + 1
+            c0 = (c0 >> 1) | (c1 << 63); c1 = (c1 >> 1) | (c2 << 63); c2 = (c2 >> 1) | (c3 << 63); c3 >>= 1;
+            u64 s0 = c0 + inc; u64 cy = s0 < inc; c0 = s0;
+            u64 s1 = c1 + cy; cy = s1 < cy; c1 = s1;
+            u64 s2 = c2 + cy; cy = s2 < cy; c2 = s2;
+            c3 += cy;
+        }
+        c.plane[r] = pl;
+    }
+    return c;
+}
+FQ_DEV u32 comb_index(const CombDigits& c, int col) {    // 4-bit table index of column `col` (wave-uniform col)
+    return (u32)((c.plane[1] >> col) & 1) | ((u32)((c.plane[2] >> col) & 1) << 1) | ((u32)((c.plane[3] >> col) & 1) << 2) |
+           ((u32)((c.plane[4] >> col) & 1) << 3);
+}
+FQ_DEV u32 comb_neg_mask(const CombDigits& c, int col) { return (u32)((c.plane[0] >> col) & 1) - 1u; }
+
 }  // namespace fq

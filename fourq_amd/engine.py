@@ -157,6 +157,31 @@ class Engine:
         out[status != 0] = 0
         return out, status
 
+    # ---- fixed-base comb (80-point table; affine outputs only) ------------------------------------
+    def comb_table(self, p_r1):
+        """960-word comb table of the order-N point `p_r1` (fourq_comb_table)."""
+        p = _host(p_r1, None).ravel()
+        if p.size != 20:
+            raise ValueError("an R1 point is 20 words")
+        out = np.empty(960, dtype=np.uint64)
+        self._ck(self._lib.fourq_comb_table(self._ctx, _ptr(p), _ptr(out)))
+        return out
+
+    def comb_mul(self, scalars, comb):
+        """Affine [m_i]B for the comb's base B: ((n, 8) words, status) -- equals R1toAffine(MUL_endo(m_i, B))."""
+        s = _host(scalars, 4)
+        t = _host(comb, None).ravel()
+        if t.size != 960:
+            raise ValueError("a comb table is 960 words")
+        out = np.empty((len(s), 8), dtype=np.uint64)
+        status = np.empty(len(s), dtype=np.uint8)
+        self._ck(self._lib.fourq_comb_mul_batch(self._ctx, _ptr(s), _ptr(t), _ptr(out), _ptr(status), len(s)))
+        return out, status
+
+    def comb_mul_dev(self, scalars, comb_host, out_affine, status, n):
+        t = _host(comb_host, None).ravel()
+        self._ck(self._lib.fourq_comb_mul_batch_dev(self._ctx, _ptr(scalars), _ptr(t), _ptr(out_affine), _ptr(status), n))
+
     # ---- point compression (32-byte wire format) -------------------------------------------------
     def encode(self, points_affine):
         """(n, 8) affine words -> (n, 32) uint8 encodings (curve4q.py:41-46)."""

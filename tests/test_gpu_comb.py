@@ -1,0 +1,79 @@
+"""Fixed-base comb: affine [m]B from an 80-point table.  Parity is at the affine level
+(the draft's "MAY use any method ... provided that it agrees", draft-ladd-cfrg-4q.md:725-729): outputs must
+equal R1toAffine(MUL_endo(m, B)) and, for B = [392]G, DH_endo(m, G)."""
+import random
+
+import numpy as np
+import pytest
+
+import curve4q_oracle as o
+import oracle_c as oc
+from fourq_amd import codec
+
+pytestmark = pytest.mark.gpu
+
+G1 = o.AffineToR1(o.Gx, o.Gy)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fourq_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def seeded_scalars(seed, n):
+    rng = random.Random(seed)
+    return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+
+
+def test_comb_table_entries(eng):
+    comb = eng.comb_table(codec.pack_point(G1)).reshape(80, 12)
+    for t in (0, 1, 15, 16, 37, 79):
+        j, u = t >> 4, t & 15
+        m = (1 << (10 * j)) * (1 + sum(((u >> r) & 1) << (50 * (r + 1)) for r in range(4)))
+        x, y = o.R1toAffine(o.MUL_endo(m % o.N, G1))
+        want = (o.f2_add(x, y), o.f2_sub(y, x), o.f2_mul(o.TWO_D, o.f2_mul(x, y)))
+        assert codec.unpack_fp2s(comb[t]) == want, t
+
+
+def test_comb_equals_mul_endo_affine(eng):
+    rng = random.Random(77)
+    B = o.MUL_endo(rng.getrandbits(256), G1)                    # a projective base point of order N
+    comb = eng.comb_table(codec.pack_point(B))
+    ms = [0, 1, 2, 3, o.N - 1, o.N, o.N + 1, 2 * o.N, (1 << 256) - 1, 1 << 255, 1 << 50, (1 << 50) - 1] + [rng.getrandbits(256) for _ in range(40)]
+    out, st = eng.comb_mul(codec.pack_scalars(ms), comb)
+    for m, got, s in zip(ms, out, st):
+        want = o.R1toAffine(o.MUL_endo(m, B))
+        if want == (o.Ox, o.Oy):
+            assert s == 2 and not got.any()
+        else:
+            assert s == 0 and codec.unpack_fp2s(got) == want, hex(m)
+
+
+def test_comb_keygen_equals_dh_fixed_base_full_batch(eng):
+    """2^18 key generations: comb([392]G) against DH_endo(m, G, table_endo([392]G)) (curve4q.py:743-762) on the GPU,
+    and a 2^12 slice against the C oracle."""
+    n = 1 << 18
+    s = seeded_scalars(8181, n)
+    g392 = codec.pack_point(o.MUL_endo(392, G1))
+    comb, te = eng.comb_table(g392), eng.table_endo(g392)
+    got, st = eng.comb_mul(s, comb)
+    gaff = np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0)
+    ref, rst = eng.dh_endo(s, gaff, te)
+    assert not st.any() and not rst.any() and np.array_equal(got, ref)
+    k = 1 << 12
+    want, wst = oc.dh(oc.ENDO, s[:k], gaff[:k])
+    assert not wst.any() and np.array_equal(got[:k], want)
+
+
+@pytest.mark.parametrize("n", [1, 255, 257])
+def test_comb_ragged(eng, n):
+    s = seeded_scalars(900 + n, n)
+    comb = eng.comb_table(codec.pack_point(G1))
+    got, st = eng.comb_mul(s, comb)
+    te = oc.table(oc.ENDO, codec.pack_point(G1))
+    full = oc.mul(oc.ENDO, s, None, te)
+    want = eng.prim("PT_R1TOAFFINE", full)
+    assert not st.any() and np.array_equal(got, want)

@@ -38,7 +38,13 @@ for lg in [int(x) for x in args.sizes.split(",")]:
     st = torch.empty(n, dtype=torch.uint8, device=dev)
     eng.dh_endo_dev(k, torch.from_numpy(np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), n, 0).view(np.int64)).to(dev), te, aff, st, n)
     torch.cuda.synchronize()
+    g392 = eng.mul_endo(codec.pack_scalars([392]), g1.reshape(1, 20))[0]
+    comb = eng.comb_table(g392)
+    t392 = eng.table_endo(g392)
+    gaff = torch.from_numpy(np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), n, 0).view(np.int64)).to(dev)
     fns = {
+        "comb": lambda: eng.comb_mul_dev(s, comb, aff_out, st, n),
+        "dh_fixed": lambda: eng.dh_endo_dev(s, gaff, t392, aff_out, st, n),
         "endo_var": lambda: eng.mul_endo_dev(s, pts, out, n),
         "endo_fixed": lambda: eng.mul_endo_fixed_dev(s, te, out, n),
         "win_var": lambda: eng.mul_windowed_dev(s, pts, out, n),
