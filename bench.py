@@ -135,7 +135,11 @@ def main():
     from fourq_amd import Engine, codec, constants
     from fourq_amd.dist import gather_rows, init_process_group
 
-    rank, local_rank, world = init_process_group("nccl")
+    # FOURQ_BENCH_REHEARSE=1: every rank on GPU 0 over gloo -- exercises the N>1 code path on a one-GPU box
+    rehearse = os.environ.get("FOURQ_BENCH_REHEARSE") == "1"
+    rank, local_rank, world = init_process_group("gloo" if rehearse else "nccl")
+    if rehearse:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
@@ -210,7 +214,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

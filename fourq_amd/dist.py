@@ -42,6 +42,8 @@ def gather_rows(local, n_total, dst=0, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        local = local.cpu()                   # rehearsals on one GPU: gloo gathers host tensors only
     sizes = [shard_bounds(n_total, r, world) for r in range(world)]
     biggest = max(hi - lo for lo, hi in sizes)
     pad = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
