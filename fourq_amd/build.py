@@ -13,9 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
-SOURCES = ["fourq_amd.hip"]
-HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"]
+SOURCES = ["fourq_amd.hip", "fourq_chain.hip"]      # two translation units: FQ_CHAIN=0 / 1 (kernels.hip.h)
+HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 
 
 def _hipcc():
@@ -37,12 +37,24 @@ def build_library(force=False, verbose=False, extra_flags=()):
     """Compile the library if it is missing or older than its sources; returns its path."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", LIB_PATH] + [os.path.join(SRC_DIR, s) for s in SOURCES]
+    objs, procs = [], []
+    for src in SOURCES:                                   # compile the translation units in parallel (~1 min each)
+        obj = os.path.join(SRC_DIR, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(SRC_DIR, src)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for cmd, proc in procs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    proc = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link), file=sys.stderr)
+    proc = subprocess.run(link, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        raise RuntimeError("link failed:\n" + proc.stdout + proc.stderr)
     return LIB_PATH
 
 

@@ -28,6 +28,13 @@ typedef uint64_t u64;
 
 #define FQ_DEV __device__ __forceinline__
 
+// FQ_CHAIN=1: GF(p^2) products keep each column's carry inside the multiply-add chain (opaque partial sums stop
+// hipcc from re-associating it into a 64-bit addition per limb): fewer instructions, less freedom for the
+// scheduler.  Pays in every kernel but the fused variable-base ones (kernels.hip.h).
+#ifndef FQ_CHAIN
+#define FQ_CHAIN 0
+#endif
+
 constexpr u32 LIMB_BITS = 26;
 constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1;
 constexpr u64 UNIT = (1ull << 26) + (1ull << 15);   // bound of a limb right after normalisation
@@ -191,6 +198,40 @@ template <int B> FQ_DEV Fe2<B + 1> fe2_conj(const Fe2<B>& a) {                  
 template <int B> FQ_DEV Fe2<2 * B> fe2_dbl(const Fe2<B>& a) { return fe2_add(a, a); }
 
 // (a0 + a1 i)(b0 + b1 i) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) i                  fields.py:167-173
+#if FQ_CHAIN
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) {
+    static_assert(cols_ok((u64)(2 * A + 1) * B), "column overflow");
+    u32 b0x8[5], b1x8[5];
+    times8(b0x8, b.re);
+    times8(b1x8, b.im);
+    Fe<A + 1> na1 = fe_neg(a.im);
+    // re and im columns advance together; each column's accumulator starts from the previous column's carry.
+    // The empty asm statements make the partial sums opaque so that hipcc keeps the carry inside the
+    // multiply-add chain instead of re-associating it into a separate 64-bit addition per limb.
+    u64 re = 0, im = 0;
+    u32 lr[5], li[5];
+#define FQ_OPAQUE(x) asm("" : "+v"(x))
+#define FQ_COL2(K)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 5; i++) {                                         \
+        const int j = K - i;                                                                \
+        const u32 q0 = j >= 0 ? b.re.l[j >= 0 ? j : 0] : b0x8[j >= 0 ? 0 : j + 5];           \
+        const u32 q1 = j >= 0 ? b.im.l[j >= 0 ? j : 0] : b1x8[j >= 0 ? 0 : j + 5];           \
+        re += (u64)a.re.l[i] * q0; FQ_OPAQUE(re);                                           \
+        im += (u64)a.re.l[i] * q1; FQ_OPAQUE(im);                                           \
+        re += (u64)na1.l[i] * q1; FQ_OPAQUE(re);                                            \
+        im += (u64)a.im.l[i] * q0; FQ_OPAQUE(im);                                           \
+    }                                                                                       \
+    lr[K] = (u32)re & LIMB_MASK; re >>= LIMB_BITS;                                          \
+    li[K] = (u32)im & LIMB_MASK; im >>= LIMB_BITS;
+    FQ_COL2(0) FQ_COL2(1) FQ_COL2(2) FQ_COL2(3) FQ_COL2(4)
+#undef FQ_COL2
+#undef FQ_OPAQUE
+    Fe2<1> r;
+    r.re = fe_finish(lr[0], lr[1], lr[2], lr[3], lr[4], re);
+    r.im = fe_finish(li[0], li[1], li[2], li[3], li[4], im);
+    return r;
+}
+#else
 template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) {
     static_assert(cols_ok((u64)(2 * A + 1) * B), "column overflow");
     u32 b0x8[5], b1x8[5];
@@ -202,7 +243,41 @@ template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) 
     r.im = fe_mac2<true>(a.re.l, b.im.l, b1x8, a.im.l, b.re.l, b0x8);
     return r;
 }
+#endif
 // (a0 + a1 i)^2 = (a0 + a1)(a0 - a1) + (2 a0 a1) i                               fields.py:176-181
+#if FQ_CHAIN
+template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
+    Fe<2 * A> s = fe_add(a.re, a.im);
+    Fe<2 * A + 1> d = fe_sub(a.re, a.im);
+    Fe<2 * A> t = fe_dbl(a.re);
+    static_assert(cols_ok((u64)(2 * A + 1) * (2 * A)), "column overflow");
+    u32 s8[5], i8[5];
+    times8(s8, s);
+    times8(i8, a.im);
+    // re = d * s and im = t * a.im advance together, carries chained as in fe2_mul
+    u64 re = 0, im = 0;
+    u32 lr[5], li[5];
+#define FQ_OPAQUE(x) asm("" : "+v"(x))
+#define FQ_COL2(K)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 5; i++) {                                         \
+        const int j = K - i;                                                                \
+        const u32 q0 = j >= 0 ? s.l[j >= 0 ? j : 0] : s8[j >= 0 ? 0 : j + 5];               \
+        const u32 q1 = j >= 0 ? a.im.l[j >= 0 ? j : 0] : i8[j >= 0 ? 0 : j + 5];            \
+        re += (u64)d.l[i] * q0; FQ_OPAQUE(re);                                              \
+        im += (u64)t.l[i] * q1; FQ_OPAQUE(im);                                              \
+    }                                                                                       \
+    lr[K] = (u32)re & LIMB_MASK; re >>= LIMB_BITS;                                          \
+    li[K] = (u32)im & LIMB_MASK; im >>= LIMB_BITS;
+    FQ_COL2(0) FQ_COL2(1) FQ_COL2(2) FQ_COL2(3) FQ_COL2(4)
+#undef FQ_COL2
+#undef FQ_OPAQUE
+    Fe2<1> r;
+    r.re = fe_finish(lr[0], lr[1], lr[2], lr[3], lr[4], re);
+    r.im = fe_finish(li[0], li[1], li[2], li[3], li[4], im);
+    return r;
+}
+
+#else
 template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
     Fe<2 * A> s = fe_add(a.re, a.im);
     Fe<2 * A + 1> d = fe_sub(a.re, a.im);
@@ -212,6 +287,8 @@ template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
     r.im = fe_mul(t, a.im);
     return r;
 }
+
+#endif
 
 // ---- canonical form, packing --------------------------------------------------------------------
 // 128-bit little-endian container (what the C ABI carries) <-> limbs.

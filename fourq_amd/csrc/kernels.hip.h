@@ -1,0 +1,298 @@
+// Shared device code of libfourq_amd.so: ladder arguments, table construction, the ladders and the kernels
+// built from them.  Included by two translation units that differ only in FQ_CHAIN (fp127.hip.h):
+//   fourq_amd.hip    FQ_CHAIN=0  fused variable-base kernels (table + ladder in one launch), primitives, C ABI
+//   fourq_chain.hip  FQ_CHAIN=1  fixed-base (LDS), two-kernel route (prep + PREBUILT ladder), comb
+// Measured on MI355X (2^20 elements): chaining each column's carry into the next column's first multiply-add
+// gains 4-10 % for every kernel of the second group and costs the fused kernels 12-15 %.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fourq_amd.h"
+#include "curve.hip.h"
+#include "recode.hip.h"
+
+namespace fq {
+
+constexpr int BLOCK = 256;
+constexpr int SLOT_U32 = 464;          // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
+constexpr int SLOT_P = 384, SLOT_Q = 424;
+constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
+
+enum Algo { ENDO = 0, WINDOWED = 1 };
+// where the ladder finds its table:
+//   FUSED     built by the same lane into its scratch slot just before the ladder (small batches: one launch)
+//   LDS       one shared table staged into LDS (fixed base)
+//   PREBUILT  built per element by prep_kernel into scratch slot `pos` (large batches: the ladder kernel then
+//             fits 128 VGPRs and runs 4 waves per SIMD instead of 1)
+enum Src { FUSED = 0, LDS = 1, PREBUILT = 2 };
+
+struct LadderArgs {
+    const u64* scalars;    // n x 4
+    const u64* points;     // variable base: n x 20 (R1) ; DH: n x 8 (affine) ; else unused
+    u64* out;              // n x 20 (R1) or n x 8 (affine, DH)
+    uint8_t* status;       // DH only
+    const u32* index;      // optional: element ids to process (mixed batches); NULL = identity
+    u32 base;              // first position of this launch (chunked large batches)
+    const u32* n_dev;      // optional: element count read on the device (mixed batches: no host round trip)
+    u32 rev;               // non-zero: ids are index[rev - 1 - pos] (the variable-base half of a partition, filled from the end)
+    const u32* table;      // fixed base: 8 x 40 limbs (global), staged to LDS
+    u32* scratch;          // variable base: SLOT_U32 per resident lane
+    u32 n;
+};
+
+// ---- small helpers -----------------------------------------------------------------------------
+FQ_DEV void store_xyz(u32* dst, const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
+    const Fe2<1>* f[3] = { &X, &Y, &Z };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { dst[10 * k + i] = f[k]->re.l[i]; dst[10 * k + 5 + i] = f[k]->im.l[i]; }
+    }
+}
+FQ_DEV void load_xyz(const u32* src, Fe2<1>& X, Fe2<1>& Y, Fe2<1>& Z) {
+    Fe2<1>* f[3] = { &X, &Y, &Z };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { f[k]->re.l[i] = src[10 * k + i]; f[k]->im.l[i] = src[10 * k + 5 + i]; }
+    }
+}
+
+// T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                       curve4q.py:179-185
+FQ_DEV void build_table_windowed(const R1& P, u32* tbl) {
+    R3 twoP = r1_to_r3(dbl(P));
+    R2 t = r1_to_r2(P);
+    store_r2_limbs(tbl, t);
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+        t = r1_to_r2(add_core(twoP, as_signed(t)));
+        store_r2_limbs(tbl + i * R2_LIMBS, t);
+    }
+}
+
+// T[k] = P + k0*phi(P) + k1*psi(P) + k2*psi(phi(P)), built in the reference's order      curve4q.py:385-403
+//   step 0: Q = phi(P) -> T[1] = Q + T[0]
+//   step 1: R = psi(P) -> T[2] = R + T[0], T[3] = R + T[1]
+//   step 2: S = psi(Q) -> T[4..7] = S + T[0..3]
+// tau and tau_dual are shared by the three steps (one code instance each): the working points P and
+// Q are parked in the lane's scratch slot so that they do not pin 60 VGPRs across the endomorphisms.
+FQ_DEV void build_table_endo(const R1& P, u32* slot) {
+    store_r2_limbs(slot, r1_to_r2(P));
+    store_xyz(slot + SLOT_P, P.X, P.Y, P.Z);
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        Fe2<1> X, Y, Z;
+        load_xyz(slot + (step == 2 ? SLOT_Q : SLOT_P), X, Y, Z);
+        Proj<1, 2, 1> t = tau(X, Y, Z);
+        Proj<2, 2, 2> u;
+        if (step == 0) {
+            u = upsilon(t);
+        } else {
+            Proj<1, 1, 1> c = chi(t);
+            u.X = widen<2>(c.X); u.Y = widen<2>(c.Y); u.Z = widen<2>(c.Z);
+        }
+        R1 V = tau_dual(u.X, u.Y, u.Z);
+        if (step == 0) store_xyz(slot + SLOT_Q, V.X, V.Y, V.Z);
+        R3 V3 = r1_to_r3(V);
+        int half = 1 << step;
+#pragma unroll 1
+        for (int m = 0; m < half; m++) {
+            R2 base = load_r2_limbs(slot + m * R2_LIMBS);
+            store_r2_limbs(slot + (half + m) * R2_LIMBS, r1_to_r2(add_core(V3, as_signed(base))));
+        }
+    }
+}
+
+// ---- the ladders -------------------------------------------------------------------------------
+template <typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
+    Proj<1, 1, 1> q4 = start_table(tbl + (e.top & 7) * stride, 0u);        // s[64] = 1: the entry itself
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+#pragma unroll 1
+    for (int i = 63; i >= 0; i--) {
+        const TP* entry = tbl + endo_digit(e, i) * stride;
+        Q = dbl(Q.X, Q.Y, Q.Z);
+        Q = add_table(Q, entry, endo_neg_mask(e, i));
+    }
+    return Q;
+}
+template <typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
+    u32 code = win_top_code(w);
+    Proj<1, 1, 1> q4 = start_table(tbl + (code & 7) * stride, (code >> 3) - 1u);
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+#pragma unroll 1
+    for (int i = 61; i >= 0; i--) {
+        code = win_code_from_window(win_window(w, i));
+        const TP* entry = tbl + (code & 7) * stride;
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) Q = dbl(Q.X, Q.Y, Q.Z);
+        Q = add_table(Q, entry, (code >> 3) - 1u);
+    }
+    return Q;
+}
+
+FQ_DEV void load_scalar(const u64* p, u64 m[4]) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    m[0] = (u64)a.x | ((u64)a.y << 32); m[1] = (u64)a.z | ((u64)a.w << 32);
+    m[2] = (u64)b.x | ((u64)b.y << 32); m[3] = (u64)b.z | ((u64)b.w << 32);
+}
+
+namespace {   // kernels: one private copy per translation unit (their code objects differ by FQ_CHAIN)
+
+// Large variable-base batches, first half: per element, (DH: membership test, cofactor clearing,) table
+// construction into scratch slot `pos`.  Kept apart from the ladder so that the endomorphisms' register
+// appetite (256 VGPRs) does not set the ladder's occupancy.
+template <int ALGO, bool DH>
+__global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
+    const u32 pos = blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= a.n) return;
+    const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
+    R1 P;
+    if (DH) {
+        Fe2<1> x = load_fe2(a.points + 8 * (size_t)id), y = load_fe2(a.points + 8 * (size_t)id + 4);
+        a.status[id] = point_on_curve(x, y) ? FOURQ_DH_OK : FOURQ_DH_NOT_ON_CURVE;
+        P = clear_cofactor_392(x, y);
+    } else {
+        P = load_r1(a.points + 20 * (size_t)id);
+    }
+    u32* slot = a.scratch + (size_t)pos * SLOT_U32;
+    if (ALGO == ENDO) build_table_endo(P, slot); else build_table_windowed(P, slot);
+}
+
+// ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
+template <int ALGO, int SRC, bool DH>
+__global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : 4];
+    if (SRC == LDS) {
+        for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
+            lds_table[(i / R2_LIMBS) * LDS_ENTRY_U32 + (i % R2_LIMBS)] = a.table[i];
+        __syncthreads();
+    }
+    const u32 n = a.n_dev ? *a.n_dev : a.n;
+    const u32 lane_slot = blockIdx.x * BLOCK + threadIdx.x;
+    const u32 lanes = gridDim.x * BLOCK;
+    const u32 n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
+#pragma unroll 1
+    for (u32 it = lane_slot; it < n_round; it += lanes) {
+        const bool live = it < n;
+        const u32 pos = live ? it : n - 1;                // idle tail lanes redo the last element, store nothing
+        const u32 id = a.index ? a.index[a.rev ? a.rev - 1 - pos : a.base + pos] : a.base + pos;
+        u64 m[4];
+        load_scalar(a.scalars + 4 * (size_t)id, m);
+        u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * SLOT_U32;
+
+        uint8_t st = FOURQ_DH_OK;
+        if (SRC == PREBUILT) {
+            if (DH) st = a.status[id];                                  // membership verdict of prep_kernel
+        } else {
+            R1 P;
+            if (DH) {
+                Fe2<1> x = load_fe2(a.points + 8 * (size_t)id), y = load_fe2(a.points + 8 * (size_t)id + 4);
+                if (!point_on_curve(x, y)) st = FOURQ_DH_NOT_ON_CURVE;  // keep going branch-free; masked at the end
+                if (SRC == FUSED) P = clear_cofactor_392(x, y);         // with a table the reference discards [392]P (curve4q.py:209)
+            } else if (SRC == FUSED) {
+                P = load_r1(a.points + 20 * (size_t)id);
+            }
+            if (SRC == FUSED) {
+                if (ALGO == ENDO) build_table_endo(P, slot); else build_table_windowed(P, slot);
+            }
+        }
+        R1 Q;
+        if (ALGO == ENDO) {
+            u64 v[4];
+            decompose(m, v);
+            EndoDigits e = recode(v);
+            Q = SRC == LDS ? ladder_endo(e, lds_table, LDS_ENTRY_U32) : ladder_endo(e, slot, R2_LIMBS);
+        } else {
+            WinScalar w = win_reduce(m);
+            Q = SRC == LDS ? ladder_windowed(w, lds_table, LDS_ENTRY_U32) : ladder_windowed(w, slot, R2_LIMBS);
+        }
+        if (DH) {
+            Fe2<1> ax, ay;
+            r1_to_affine(Q, ax, ay);
+            u64 o[8];
+            store_fe2(o, ax); store_fe2(o + 4, ay);
+            bool neutral = (o[0] | o[1] | o[2] | o[3] | o[5] | o[6] | o[7]) == 0 && o[4] == 1;   // (Ox, Oy) = ((0,0),(1,0))
+            if (st == FOURQ_DH_OK && neutral) st = FOURQ_DH_NEUTRAL;
+            if (live) {
+                uint4* dst = reinterpret_cast<uint4*>(a.out + 8 * (size_t)id);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    u64 lo = st ? 0 : o[2 * k], hi = st ? 0 : o[2 * k + 1];
+                    dst[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+                }
+                a.status[id] = st;
+            }
+        } else if (live) {
+            u64 o[20];
+            store_r1(o, Q);
+            uint4* dst = reinterpret_cast<uint4*>(a.out + 20 * (size_t)id);
+#pragma unroll
+            for (int k = 0; k < 10; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
+        }
+    }
+}
+
+// ---- fixed-base comb -------------------------------------------------------------
+constexpr int COMB_POINTS = COMB_V << (COMB_W - 1);          // 80
+constexpr int COMB_ENTRY_U32 = 3 * COORD_U32;                 // (x+y, y-x, 2dxy)
+constexpr int COMB_LDS_U32 = COMB_ENTRY_U32 + 4;              // padded stride in LDS
+
+#if FQ_CHAIN   // only fourq_chain.hip launches it
+// [m]B, affine, from the comb: 9 doublings + 49 mixed additions per element
+__global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
+    __shared__ __attribute__((aligned(16))) u32 lds[COMB_POINTS * COMB_LDS_U32];
+    for (int i = threadIdx.x; i < COMB_POINTS * COMB_ENTRY_U32; i += BLOCK)
+        lds[(i / COMB_ENTRY_U32) * COMB_LDS_U32 + (i % COMB_ENTRY_U32)] = comb_limbs[i];
+    __syncthreads();
+    const u32 lanes = gridDim.x * BLOCK;
+    const u32 n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
+#pragma unroll 1
+    for (u32 it = blockIdx.x * BLOCK + threadIdx.x; it < n_round; it += lanes) {
+        const bool live = it < n;
+        const u32 id = live ? it : n - 1;
+        u64 m[4];
+        load_scalar(scalars + 4 * (size_t)id, m);
+        CombDigits c = comb_recode(m);
+        R1 Q;
+#pragma unroll 1
+        for (int i = COMB_E - 1; i >= 0; i--) {
+#pragma unroll 1
+            for (int j = 0; j < COMB_V; j++) {
+                const int col = COMB_E * j + i;
+                const u32* entry = lds + ((j << (COMB_W - 1)) + comb_index(c, col)) * COMB_LDS_U32;
+                const u32 neg = comb_neg_mask(c, col);
+                if (i == COMB_E - 1 && j == 0) { Q = affine_table_start(entry, neg); continue; }
+                if (j == 0) Q = dbl(Q.X, Q.Y, Q.Z);
+                Q = add_affine_table(Q, entry, neg);
+            }
+        }
+        Fe2<1> ax, ay;
+        r1_to_affine(Q, ax, ay);
+        ax = fe2_carry(fe2_cneg(ax, c.negate));               // even scalar: [k]B = -[N - k]B, -(x, y) = (-x, y)
+        u64 o[8];
+        store_fe2(o, ax); store_fe2(o + 4, ay);
+        const bool neutral = (o[0] | o[1] | o[2] | o[3] | o[5] | o[6] | o[7]) == 0 && o[4] == 1;
+        if (live) {
+            uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)id);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u64 lo = neutral ? 0 : o[2 * k], hi = neutral ? 0 : o[2 * k + 1];
+                dst[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+            }
+            status[id] = neutral ? FOURQ_DH_NEUTRAL : FOURQ_DH_OK;
+        }
+    }
+}
+
+#endif
+
+}  // namespace
+
+// launchers implemented in fourq_chain.hip (FQ_CHAIN=1 code objects)
+int chain_launch_ladder(int algo, int src, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int chain_launch_prep(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n);
+
+}  // namespace fq
