@@ -198,8 +198,7 @@ template <int B> FQ_DEV Fe2<B + 1> fe2_conj(const Fe2<B>& a) {                  
 template <int B> FQ_DEV Fe2<2 * B> fe2_dbl(const Fe2<B>& a) { return fe2_add(a, a); }
 
 // (a0 + a1 i)(b0 + b1 i) = (a0 b0 - a1 b1) + (a0 b1 + a1 b0) i                  fields.py:167-173
-#if FQ_CHAIN
-template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) {
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul_chain(const Fe2<A>& a, const Fe2<B>& b) {
     static_assert(cols_ok((u64)(2 * A + 1) * B), "column overflow");
     u32 b0x8[5], b1x8[5];
     times8(b0x8, b.re);
@@ -231,8 +230,7 @@ template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) 
     r.im = fe_finish(li[0], li[1], li[2], li[3], li[4], im);
     return r;
 }
-#else
-template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) {
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul_plain(const Fe2<A>& a, const Fe2<B>& b) {
     static_assert(cols_ok((u64)(2 * A + 1) * B), "column overflow");
     u32 b0x8[5], b1x8[5];
     times8(b0x8, b.re);
@@ -243,10 +241,13 @@ template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) 
     r.im = fe_mac2<true>(a.re.l, b.im.l, b1x8, a.im.l, b.re.l, b0x8);
     return r;
 }
-#endif
+// CH selects the variant per call site; the plain name follows the translation unit's default
+template <bool CH, int A, int B> FQ_DEV Fe2<1> fe2_mulx(const Fe2<A>& a, const Fe2<B>& b) {
+    if constexpr (CH) return fe2_mul_chain(a, b); else return fe2_mul_plain(a, b);
+}
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) { return fe2_mulx<FQ_CHAIN != 0>(a, b); }
 // (a0 + a1 i)^2 = (a0 + a1)(a0 - a1) + (2 a0 a1) i                               fields.py:176-181
-#if FQ_CHAIN
-template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
+template <int A> FQ_DEV Fe2<1> fe2_sqr_chain(const Fe2<A>& a) {
     Fe<2 * A> s = fe_add(a.re, a.im);
     Fe<2 * A + 1> d = fe_sub(a.re, a.im);
     Fe<2 * A> t = fe_dbl(a.re);
@@ -277,8 +278,7 @@ template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
     return r;
 }
 
-#else
-template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
+template <int A> FQ_DEV Fe2<1> fe2_sqr_plain(const Fe2<A>& a) {
     Fe<2 * A> s = fe_add(a.re, a.im);
     Fe<2 * A + 1> d = fe_sub(a.re, a.im);
     Fe<2 * A> t = fe_dbl(a.re);
@@ -288,7 +288,10 @@ template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) {
     return r;
 }
 
-#endif
+template <bool CH, int A> FQ_DEV Fe2<1> fe2_sqrx(const Fe2<A>& a) {
+    if constexpr (CH) return fe2_sqr_chain(a); else return fe2_sqr_plain(a);
+}
+template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) { return fe2_sqrx<FQ_CHAIN != 0>(a); }
 
 // ---- canonical form, packing --------------------------------------------------------------------
 // 128-bit little-endian container (what the C ABI carries) <-> limbs.
