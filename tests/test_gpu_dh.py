@@ -131,3 +131,17 @@ def test_full_size_cfg4_shard_exchange_symmetry(eng):
     mid, st = oc.dh(oc.ENDO, b[:k], gk)
     want, st2 = oc.dh(oc.ENDO, a[:k], mid)
     assert not st.any() and not st2.any() and np.array_equal(ab[:k], want)
+
+
+def test_reference_self_test_sequence_on_the_gpu():
+    """The reference's own self-tests (curve4q.py:473-790, fields.py:366-409) through the drop-in API: every line
+    must read [PASS], including the 1000-step doubleP / P1000 / mulP / phiP / psiP chains."""
+    import io
+    from fourq_amd import selftest
+    buf = io.StringIO()
+    failed = selftest.run(loops=1000, dh_loops=4, seed=2026, out=buf)
+    text = buf.getvalue()
+    assert failed == 0 and "[FAIL]" not in text, text
+    assert text.count("[PASS]") >= 45
+    for label in ("double", "addition", "mul-windowed", "mul-endo", "phi", "psi", "encode", "decode", "DH-endo-symm", "DH-reject-392-torsion"):
+        assert "[PASS] %s\n" % label in text

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""One-off parity soak at the largest BASELINE.json size (2^22 elements): every output of every batched entry
+point against the C oracle.  Test infrastructure (uses oracle/); run on the GPU box, result kept in profiles/."""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import curve4q_oracle as o
+import oracle_c as oc
+from fourq_amd import Engine, codec
+
+LG = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+n = 1 << LG
+
+
+def scalars(seed):
+    return np.frombuffer(random.Random(seed).getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+
+
+G1 = o.AffineToR1(o.Gx, o.Gy)
+g1 = codec.pack_point(G1)
+with Engine(0) as eng:
+    te, tw = eng.table_endo(g1), eng.table_windowed(g1)
+    s = scalars(1)
+    pts = eng.mul_endo_fixed(scalars(2), te)
+    checks = [
+        ("MUL_endo variable base", lambda: eng.mul_endo(s, pts), lambda: oc.mul(oc.ENDO, s, pts)),
+        ("MUL_windowed variable base", lambda: eng.mul_windowed(s, pts), lambda: oc.mul(oc.WINDOWED, s, pts)),
+        ("MUL_endo fixed base", lambda: eng.mul_endo_fixed(s, te), lambda: oc.mul(oc.ENDO, s, None, te)),
+        ("MUL_windowed fixed base", lambda: eng.mul_windowed_fixed(s, tw), lambda: oc.mul(oc.WINDOWED, s, None, tw)),
+    ]
+    for name, gpu, cpu in checks:
+        t0 = time.time(); a = gpu(); t1 = time.time(); b = cpu(); t2 = time.time()
+        print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  C oracle %.1fs  identical=%s" % (name, LG, t1 - t0, t2 - t1, np.array_equal(a, b)), flush=True)
+        assert np.array_equal(a, b)
+    aff, st = eng.dh_endo(scalars(3), np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0), te if False else None)
+    assert not st.any()
+    for name, gpu, cpu in (("DH_endo variable base", lambda: eng.dh_endo(s, aff), lambda: oc.dh(oc.ENDO, s, aff)),
+                           ("DH_windowed variable base", lambda: eng.dh_windowed(s, aff), lambda: oc.dh(oc.WINDOWED, s, aff))):
+        t0 = time.time(); a, sa = gpu(); t1 = time.time(); b, sb = cpu(); t2 = time.time()
+        ok = np.array_equal(a, b) and np.array_equal(sa, sb)
+        print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  C oracle %.1fs  identical=%s" % (name, LG, t1 - t0, t2 - t1, ok), flush=True)
+        assert ok
+    g392 = codec.pack_point(o.MUL_endo(392, G1))
+    comb = eng.comb_table(g392)
+    a, sa = eng.comb_mul(s, comb)
+    gaff = np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0)
+    b, sb = oc.dh(oc.ENDO, s, gaff)
+    ok = np.array_equal(a, b) and np.array_equal(sa, sb)
+    print("%-28s n=2^%d  identical=%s" % ("comb keygen == DH_endo(m, G)", LG, ok), flush=True)
+    assert ok
+    enc = eng.encode(a)
+    dec, dst = eng.decode(enc)
+    ok = not dst.any() and np.array_equal(dec, a)
+    print("%-28s n=2^%d  identical=%s" % ("decode(encode(P)) == P", LG, ok), flush=True)
+    assert ok
+print("SOAK OK")
