@@ -84,7 +84,13 @@ FQ_DEV void build_table_endo(const R1& P, u32* slot) {
     for (int step = 0; step < 3; step++) {
         Fe2<1> X, Y, Z;
         load_xyz(slot + (step == 2 ? SLOT_Q : SLOT_P), X, Y, Z);
-        Proj<1, 2, 1> t = tau(X, Y, Z);
+        Proj<1, 2, 1> t;
+        if (step == 1) {                 // tau(P), parked by step 0 in P's place (phi and psi share it, curve4q.py:318-322)
+            t.X = X; t.Y = widen<2>(Y); t.Z = Z;
+        } else {
+            t = tau(X, Y, Z);
+            if (step == 0) store_xyz(slot + SLOT_P, t.X, fe2_carry(t.Y), t.Z);
+        }
         Proj<2, 2, 2> u;
         if (step == 0) {
             u = upsilon(t);
