@@ -103,18 +103,20 @@ def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
 
 
 # per-workload constants: algorithmic bytes per unit and v_mad_u64_u32 issued per unit by this
-# implementation
+# implementation, counted from the formulas: GF(p^2) M = 100, S = 50; DBL = 3M+4S = 500,
+# ADD = 8M = 800; ladder step 1 300 (x64 endo, 4 DBL + ADD = 2 800 x62 windowed); table_endo 14 300;
+# DH extras (membership, x392, inversion) 8 600; comb 9 DBL + 49 mixed ADD (7M) + inversion = 37 000
 WORKLOADS = {
-    "cfg2": dict(batch=1 << 16, bytes=32 + 160 + 160, mads=100_100, kernel="ladder_kernel<ENDO, FUSED>",
+    "cfg2": dict(batch=1 << 16, bytes=32 + 160 + 160, mads=97_600, kernel="ladder_kernel<ENDO, FUSED>",
                  text="BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
                       "projective N-torsion points, raw R1 in/out resident in HBM"),
-    "cfg3": dict(batch=1 << 20, bytes=32 + 160, mads=164_000, kernel="ladder_kernel<WINDOWED, LDS>",
+    "cfg3": dict(batch=1 << 20, bytes=32 + 160, mads=173_600, kernel="ladder_kernel<WINDOWED, LDS>",
                  text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
-    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=42_000 + 100_100 + 11_000, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH>",
+    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=37_000 + 97_600 + 8_600, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH>",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
                       "(first half fixed-base through the 80-point comb of [392]G, same affine outputs as with table_endo([392]G); "
                       "second half variable-base); affine in/out"),
-    "cfg5": dict(batch=1 << 17, bytes=(192 + 352) // 2, mads=(83_300 + 100_100) // 2, kernel="ladder_kernel<ENDO, LDS> + ladder_kernel<ENDO, FUSED> over a device-side partition",
+    "cfg5": dict(batch=1 << 17, bytes=(192 + 352) // 2, mads=(83_300 + 97_600) // 2, kernel="ladder_kernel<ENDO, LDS> + ladder_kernel<ENDO, FUSED> over a device-side partition",
                  text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo"),
 }
 
