@@ -138,7 +138,7 @@ template <bool CH = (FQ_CHAIN != 0), bool PRELOAD = false, typename TP> FQ_DEV R
     }
     return Q;
 }
-template <typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
+template <bool CH = (FQ_CHAIN != 0), bool PRELOAD = false, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
     Proj<1, 1, 1> q4 = start_table(tbl + (code & 7) * stride, (code >> 3) - 1u);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
@@ -146,9 +146,17 @@ template <typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* t
     for (int i = 61; i >= 0; i--) {
         code = win_code_from_window(win_window(w, i));
         const TP* entry = tbl + (code & 7) * stride;
+        const u32 neg = (code >> 3) - 1u;
+        if (PRELOAD) {
+            EntryRegs t = load_entry(entry, neg);
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) Q = dbl(Q.X, Q.Y, Q.Z);
-        Q = add_table(Q, entry, (code >> 3) - 1u);
+            for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
+            Q = add_entry<CH>(Q, t, neg);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
+            Q = add_table<CH>(Q, entry, neg);
+        }
     }
     return Q;
 }
@@ -229,7 +237,8 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(e, slot, R2_LIMBS);
         } else {
             WinScalar w = win_reduce(m);
-            Q = SRC == LDS ? ladder_windowed(w, lds_table, LDS_ENTRY_U32) : ladder_windowed(w, slot, R2_LIMBS);
+            constexpr bool CH = (FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN);
+            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(w, slot, R2_LIMBS);
         }
         if (DH) {
             Fe2<1> ax, ay;
