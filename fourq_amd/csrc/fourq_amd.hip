@@ -1,18 +1,20 @@
-// libfourq_amd.so -- HIP kernels and the C ABI declared in include/fourq_amd.h.
+// libfourq_amd.so -- first translation unit: the fused variable-base kernels, the small service kernels
+// (tables, partition, wire format, primitives) and the C ABI declared in include/fourq_amd.h.  The
+// fixed-base, two-kernel-route and comb kernels live in fourq_chain.hip; shared device code in kernels.hip.h.
 //
 // Kernel design (gfx950): one wavefront lane owns one (scalar, point) pair for the whole scalar
 // multiplication.  Lanes never communicate; a workgroup is 256 lanes; the grid is sized to the
-// number of resident lanes and strides over the batch, so per-lane table scratch is sized by
-// residency, not by batch size.
+// number of resident lanes and strides over the batch.
 //
-//   variable base : the lane builds its own 8-entry R2 table (table_endo / table_windowed) into a
-//                   1.5 KiB slot of HBM scratch (one 160-byte line group per entry), then each
-//                   ladder step gathers the entry its digit selects (wavefront-level gather, one
-//                   entry per lane) while the doubling runs.
+//   variable base : the lane builds its own 8-entry R2 table (table_endo / table_windowed) into a 1 856-byte
+//                   slot of HBM scratch (192 bytes per entry), then each ladder step gathers the coordinates
+//                   of the entry its digit selects (wavefront-level gather, one entry per lane) a whole
+//                   doubling ahead of their use.
 //   fixed base    : the 8-entry table is staged once per workgroup into LDS (padded to dodge bank
 //                   conflicts) and gathered from there.
-//   selection     : the sign of a digit is applied branch-free (mask selects); the table index is
-//                   a per-lane address, as in the reference (curve4q.py:232, :440).
+//   selection     : the sign of a digit is applied branch-free (address choice for the N/D swap, a two-op
+//                   conditional negation for F); the table index is a per-lane address, as in the reference
+//                   (curve4q.py:232, :440).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -29,7 +31,7 @@ using namespace fq;
 
 namespace {
 
-// packed table (8 x 16 words) -> working limbs (8 x 40 u32)
+// packed table (8 x 16 words) -> working limbs (8 x 48 u32)
 __global__ void table_unpack_kernel(const u64* packed, u32* limbs) {
     int k = threadIdx.x;
     if (k < 8) store_r2_limbs(limbs + k * R2_LIMBS, load_r2_packed(packed + 16 * k));

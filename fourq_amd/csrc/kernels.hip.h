@@ -3,7 +3,8 @@
 //   fourq_amd.hip    FQ_CHAIN=0  fused variable-base kernels (table + ladder in one launch), primitives, C ABI
 //   fourq_chain.hip  FQ_CHAIN=1  fixed-base (LDS), two-kernel route (prep + PREBUILT ladder), comb
 // Measured on MI355X (2^20 elements): chaining each column's carry into the next column's first multiply-add
-// gains 4-10 % for every kernel of the second group and costs the fused kernels 12-15 %.
+// gains 4-10 % for every kernel of the second group and costs the fused kernels 12-15 % when applied wholesale;
+// the fused kernels therefore use it only in their ladders, with preloaded table entries (see below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,8 +37,8 @@ struct LadderArgs {
     u32 base;              // first position of this launch (chunked large batches)
     const u32* n_dev;      // optional: element count read on the device (mixed batches: no host round trip)
     u32 rev;               // non-zero: ids are index[rev - 1 - pos] (the variable-base half of a partition, filled from the end)
-    const u32* table;      // fixed base: 8 x 40 limbs (global), staged to LDS
-    u32* scratch;          // variable base: SLOT_U32 per resident lane
+    const u32* table;      // fixed base: 8 x 48 working limbs (global), staged to LDS
+    u32* scratch;          // variable base: SLOT_U32 per resident lane (FUSED) or per position of the chunk (PREBUILT)
     u32 n;
 };
 
