@@ -23,6 +23,10 @@
  * contexts are independent.  There is no CPU fallback: without a usable gfx950 device
  * fourq_ctx_create fails.
  *
+ * A context owns device scratch (per-lane look-up tables, staging) that its launches reuse in stream order:
+ * let the current stream's work finish (fourq_ctx_sync or the caller's own synchronisation) before handing the
+ * context another stream with fourq_ctx_set_stream.
+ *
  * Pointer flavours: functions ending in _dev take DEVICE pointers, enqueue on the context's
  * stream and return without synchronising (use fourq_ctx_sync or the caller's stream).  The same
  * names without _dev take HOST pointers and are synchronous (H2D copy, kernel, D2H copy).
