@@ -102,17 +102,47 @@ def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
             "per_core": round(per_core / busy, 1)}
 
 
+def edge_case_check(eng):
+    """SURVEY.md 8d: every run carries an edge-case mini-batch -- scalars {0,1,2,N-1,N,N+1,2N,2^255,2^256-1}
+    on G and -G through MUL_endo, MUL_windowed and DH_endo, bit-exact against the Python oracle (part of the
+    cpu_baseline leg: the oracle is the checker).  Returns the number of cases."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import curve4q_oracle as o
+    from fourq_amd import codec
+    N = o.N
+    ms = [0, 1, 2, N - 1, N, N + 1, 2 * N, 1 << 255, (1 << 256) - 1]
+    G = (o.Gx, o.Gy)
+    negG = (o.GFp2.neg(o.Gx), o.Gy)
+    cases = [(m, A) for A in (G, negG) for m in ms]
+    s = codec.pack_scalars([m for m, _ in cases])
+    r1 = codec.pack_points([o.AffineToR1(*A) for _, A in cases], 5)
+    aff = codec.pack_points([A for _, A in cases], 2)
+    for name, got, want in (("MUL_endo", eng.mul_endo(s, r1), o.MUL_endo), ("MUL_windowed", eng.mul_windowed(s, r1), o.MUL_windowed)):
+        if codec.unpack_points(got) != [want(m, o.AffineToR1(*A)) for m, A in cases]:
+            raise SystemExit("PARITY FAILURE: %s on the edge-case mini-batch" % name)
+    out, status = eng.dh_endo(s, aff)
+    for (m, A), row, st in zip(cases, codec.unpack_points(out), status):
+        try:
+            want, code = o.DH_endo(m, A), 0
+        except Exception as exc:            # the reference's two rejections (curve4q.py:448, :460)
+            want, code = None, (1 if "not on curve" in str(exc) else 2)
+        if int(st) != code or (code == 0 and row != want):
+            raise SystemExit("PARITY FAILURE: DH_endo on the edge-case mini-batch (m=%d)" % m)
+    return 3 * len(cases)
+
+
 # per-workload constants: algorithmic bytes per unit (SURVEY.md 8d) and v_mad_u64_u32 issued per unit by this
 # implementation, counted from the formulas (DESIGN.md section 5): GF(p^2) M = 100, S = 50; DBL = 3M+4S = 500,
 # ADD = 8M = 800; ladder step 1 300 (x64 endo, 4 DBL + ADD = 2 800 x62 windowed); table_endo 14 300;
-# DH extras (membership, x392, inversion) 8 600; comb 9 DBL + 49 mixed ADD (7M) + inversion = 37 000
+# DH extras (membership, x392, inversion) 8 600; comb 9 DBL + 49 mixed ADD (7M) + inversion = 37 000; at cfg4's size
+# eight elements share one inversion (normalize_kernel<8>): -1 800 per DH_core
 WORKLOADS = {
     "cfg2": dict(batch=1 << 16, bytes=32 + 160 + 160, mads=97_600, kernel="ladder_kernel<ENDO, FUSED>",
                  text="BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
                       "projective N-torsion points, raw R1 in/out resident in HBM"),
     "cfg3": dict(batch=1 << 20, bytes=32 + 160, mads=173_600, kernel="ladder_kernel<WINDOWED, LDS>",
                  text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
-    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=37_000 + 97_600 + 8_600, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH>",
+    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=35_200 + 97_600 + 6_800, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
                       "(first half fixed-base through the 80-point comb of [392]G, same affine outputs as with table_endo([392]G); "
                       "second half variable-base); affine in/out"),
@@ -262,6 +292,7 @@ def main():
                 pts = codec.unpack_points(points.cpu().numpy().view(np.uint64))
                 items = [(m, P if f else None) for m, P, f in zip(ms, pts, flags_h)]
                 line["cpu_baseline"] = cpu_baseline("mixed", items, codec.unpack_table(extra_h), expected, "50/50 fixed/variable MUL_endo")
+            line["cpu_baseline"]["sample"] += "; plus %d edge-case scalar/point pairs (0, 1, 2, N-1, N, N+1, 2N, 2^255, 2^256-1 on +-G), exact" % edge_case_check(eng)
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

@@ -234,6 +234,9 @@ struct fourq_ctx {
     size_t part_capacity = 0;
     hipStream_t aux_stream = nullptr;   // the variable-base half of a mixed batch runs beside the fixed-base half
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
+    size_t proj_capacity = 0;
+    int norm_k = -1;               // FOURQ_NORM_K: 0 = always invert per element, 2/4/8 = always batch; -1 = by batch size
     void* stage = nullptr;         // staging for the host-pointer API
     size_t stage_bytes = 0;
     char err[256] = { 0 };
@@ -282,9 +285,11 @@ template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs
 // Measured on MI355X at 2^20 elements: the two-kernel route gains for MUL_windowed and DH_* and is on par for
 // plain MUL_endo, whose 64-step ladder hardly amortises the second launch and the colder table gathers (4 waves
 // per SIMD put 486 MB of tables in flight, past the Infinity Cache); plain MUL_endo therefore stays fused.
+bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
+    return (algo == WINDOWED || dh || c->split_all) && n >= c->split_min;
+}
 template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
-    const bool split = (ALGO == WINDOWED || DH || c->split_all) && a.n >= c->split_min;
-    if (!split) return launch_ladder<ALGO, FUSED, DH>(c, a);
+    if (!takes_split_route(c, ALGO, DH, a.n)) return launch_ladder<ALGO, FUSED, DH>(c, a);
     const u32 total = a.n;
     for (u32 off = 0; off < total; off += (u32)c->split_chunk) {
         LadderArgs part = a;
@@ -295,6 +300,22 @@ template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
         int rc = launch_ladder<ALGO, PREBUILT, DH>(c, part);
         if (rc) return rc;
     }
+    return FOURQ_OK;
+}
+
+// DH outputs are affine: from two resident generations of lanes upwards each lane meets several elements, and
+// the inversions of K of them are merged into one (normalize_kernel).  Returns K (0: invert per element).
+int normalize_group(const fourq_ctx* c, size_t n) {
+    if (c->norm_k >= 0) return n >= (size_t)c->norm_k ? c->norm_k : 0;
+    for (int k = 8; k >= 2; k >>= 1) if (n >= (size_t)k * c->lanes) return k;
+    return 0;
+}
+int ensure_proj(fourq_ctx* c, size_t n) {
+    if (n <= c->proj_capacity) return FOURQ_OK;
+    if (c->proj) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->proj)); c->proj = nullptr; c->proj_capacity = 0; }
+    size_t want = n + n / 4;
+    HIP_TRY(c, hipMalloc(&c->proj, want * PROJ_PLANES * sizeof(uint4)));
+    c->proj_capacity = want;
     return FOURQ_OK;
 }
 
@@ -325,10 +346,25 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
     DeviceGuard g(c->device);
     LadderArgs a = {};
     a.scalars = scalars; a.points = points; a.out = out; a.status = status; a.n = (u32)n;
-    if (!table) return algo == ENDO ? launch_variable<ENDO, true>(c, a) : launch_variable<WINDOWED, true>(c, a);
-    int rc = stage_table(c, table);
+    int group = normalize_group(c, n);
+    if (!table) {                                  // fused kernels invert in place; the prep + ladder route always defers
+        const bool split = takes_split_route(c, algo, true, n);
+        group = split ? (group ? group : 1) : 0;
+    }
+    int rc = group ? ensure_proj(c, n) : FOURQ_OK;
     if (rc) return rc;
-    return algo == ENDO ? launch_ladder<ENDO, LDS, true>(c, a) : launch_ladder<WINDOWED, LDS, true>(c, a);
+    a.proj = group ? c->proj : nullptr;
+    a.proj_stride = (u32)c->proj_capacity;
+    if (!table) {
+        rc = algo == ENDO ? launch_variable<ENDO, true>(c, a) : launch_variable<WINDOWED, true>(c, a);
+    } else {
+        rc = stage_table(c, table);
+        if (rc) return rc;
+        rc = algo == ENDO ? launch_ladder<ENDO, LDS, true>(c, a) : launch_ladder<WINDOWED, LDS, true>(c, a);
+    }
+    if (rc || !group) return rc;
+    HIPRC_TRY(c, chain_launch_normalize(group, c->stream, c->proj, (u32)c->proj_capacity, out, status, (u32)n));
+    return FOURQ_OK;
 }
 
 // host-pointer wrappers: one staging buffer carved into [scalars | points | out | status]
@@ -428,6 +464,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         c->split_min = 2 * c->lanes;                       // below two full waves of fused work the second launch does not pay
         if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
+        if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
         c->split_chunk = c->lanes_w4;
         if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }
         size_t slots = c->lanes > c->lanes_w4 ? c->lanes : c->lanes_w4;
@@ -451,6 +488,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     DeviceGuard g(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->proj) (void)hipFree(c->proj);
     if (c->table_limbs) (void)hipFree(c->table_limbs);
     if (c->table_packed) (void)hipFree(c->table_packed);
     if (c->part_counters) (void)hipFree(c->part_counters);
@@ -631,8 +669,13 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     HIP_TRY(c, hipMemcpyAsync(c->comb_packed, comb, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(comb_unpack_kernel, dim3(1), dim3(128), 0, c->stream, c->comb_packed, c->comb_limbs);
     HIP_TRY(c, hipGetLastError());
+    const int group = normalize_group(c, n);
+    int rc = group ? ensure_proj(c, n) : FOURQ_OK;
+    if (rc) return rc;
     size_t blocks = (n + BLOCK - 1) / BLOCK, blocks_max = c->lanes_w4 / BLOCK;
-    HIPRC_TRY(c, chain_launch_comb((unsigned)(blocks < blocks_max ? blocks : blocks_max), c->stream, scalars, c->comb_limbs, out, status, (u32)n));
+    HIPRC_TRY(c, chain_launch_comb((unsigned)(blocks < blocks_max ? blocks : blocks_max), c->stream, scalars, c->comb_limbs, out, status,
+                                   group ? c->proj : nullptr, (u32)c->proj_capacity, (u32)n));
+    if (group) HIPRC_TRY(c, chain_launch_normalize(group, c->stream, c->proj, (u32)c->proj_capacity, out, status, (u32)n));
     return FOURQ_OK;
 }
 FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {

@@ -1,6 +1,6 @@
 // Second translation unit of libfourq_amd.so: the kernels that profit from chained carries (FQ_CHAIN=1, see
 // kernels.hip.h): fixed-base ladders (table in LDS), the two-kernel route for large variable-base batches
-// (prep_kernel + ladder_kernel<PREBUILT>) and the fixed-base comb.  Only launchers are exported to the other
+// (prep_kernel + ladder_kernel<PREBUILT>), the fixed-base comb and the batched normalisation.  Only launchers are exported to the other
 // translation unit; the C ABI lives in fourq_amd.hip.
 #ifndef FQ_CHAIN
 #define FQ_CHAIN 1
@@ -10,18 +10,23 @@
 namespace fq {
 
 namespace {
-template <int ALGO, int SRC, bool DH> int launch(unsigned grid, hipStream_t stream, const LadderArgs& a) {
-    hipLaunchKernelGGL((ladder_kernel<ALGO, SRC, DH>), dim3(grid), dim3(BLOCK), 0, stream, a);
+template <int ALGO, int SRC, bool DH, bool DEFER> int launch(unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    hipLaunchKernelGGL((ladder_kernel<ALGO, SRC, DH, DEFER>), dim3(grid), dim3(BLOCK), 0, stream, a);
     return (int)hipGetLastError();
 }
-template <int ALGO, int SRC> int launch_dh(bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
-    return dh ? launch<ALGO, SRC, true>(grid, stream, a) : launch<ALGO, SRC, false>(grid, stream, a);
+template <int ALGO> int launch_algo(int src, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    if (src == LDS) {
+        if (!dh) return launch<ALGO, LDS, false, false>(grid, stream, a);
+        return a.proj ? launch<ALGO, LDS, true, true>(grid, stream, a) : launch<ALGO, LDS, true, false>(grid, stream, a);
+    }
+    if (!dh) return launch<ALGO, PREBUILT, false, false>(grid, stream, a);
+    if (!a.proj) return (int)hipErrorInvalidValue;           // the PREBUILT DH ladder always defers normalisation
+    return launch<ALGO, PREBUILT, true, true>(grid, stream, a);
 }
 }  // namespace
 
 int chain_launch_ladder(int algo, int src, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
-    if (src == LDS) return algo == ENDO ? launch_dh<ENDO, LDS>(dh, grid, stream, a) : launch_dh<WINDOWED, LDS>(dh, grid, stream, a);
-    return algo == ENDO ? launch_dh<ENDO, PREBUILT>(dh, grid, stream, a) : launch_dh<WINDOWED, PREBUILT>(dh, grid, stream, a);
+    return algo == ENDO ? launch_algo<ENDO>(src, dh, grid, stream, a) : launch_algo<WINDOWED>(src, dh, grid, stream, a);
 }
 int chain_launch_prep(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
     if (algo == ENDO) {
@@ -33,8 +38,17 @@ int chain_launch_prep(int algo, bool dh, unsigned grid, hipStream_t stream, cons
     }
     return (int)hipGetLastError();
 }
-int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
-    hipLaunchKernelGGL(comb_kernel, dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, n);
+int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
+    if (proj) hipLaunchKernelGGL(comb_kernel<true>, dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
+    else hipLaunchKernelGGL(comb_kernel<false>, dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
+    return (int)hipGetLastError();
+}
+int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n) {
+    const unsigned grid = ((n + k - 1) / k + BLOCK - 1) / BLOCK;
+    if (k == 8) hipLaunchKernelGGL(normalize_kernel<8>, dim3(grid), dim3(BLOCK), 0, stream, proj, proj_stride, out, status, n);
+    else if (k == 4) hipLaunchKernelGGL(normalize_kernel<4>, dim3(grid), dim3(BLOCK), 0, stream, proj, proj_stride, out, status, n);
+    else if (k == 2) hipLaunchKernelGGL(normalize_kernel<2>, dim3(grid), dim3(BLOCK), 0, stream, proj, proj_stride, out, status, n);
+    else hipLaunchKernelGGL(normalize_kernel<1>, dim3(grid), dim3(BLOCK), 0, stream, proj, proj_stride, out, status, n);
     return (int)hipGetLastError();
 }
 

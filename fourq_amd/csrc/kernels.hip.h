@@ -18,6 +18,7 @@ namespace fq {
 constexpr int BLOCK = 256;
 constexpr int SLOT_U32 = 464;          // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
 constexpr int SLOT_P = 384, SLOT_Q = 424;
+constexpr int PROJ_PLANES = 8;            // deferred normalisation: the 30 working limbs of (X, Y, Z) in eight uint4 planes
 constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
 
 enum Algo { ENDO = 0, WINDOWED = 1 };
@@ -39,6 +40,9 @@ struct LadderArgs {
     u32 rev;               // non-zero: ids are index[rev - 1 - pos] (the variable-base half of a partition, filled from the end)
     const u32* table;      // fixed base: 8 x 48 working limbs (global), staged to LDS
     u32* scratch;          // variable base: SLOT_U32 per resident lane (FUSED) or per position of the chunk (PREBUILT)
+    uint4* proj;           // DH, optional: PROJ_PLANES x proj_stride; non-NULL selects the kernels that leave (X, Y, Z)
+                           // there for normalize_kernel (always the case on the PREBUILT route)
+    u32 proj_stride;       // elements per plane
     u32 n;
 };
 
@@ -58,6 +62,34 @@ FQ_DEV void load_xyz(const u32* src, Fe2<1>& X, Fe2<1>& Y, Fe2<1>& Z) {
 #pragma unroll
         for (int i = 0; i < 5; i++) { f[k]->re.l[i] = src[10 * k + i]; f[k]->im.l[i] = src[10 * k + 5 + i]; }
     }
+}
+
+// (X, Y, Z) of element `id` for normalize_kernel: plane p holds limbs 4p .. 4p+3 of the 30-limb record
+// X.re X.im Y.re Y.im Z.re Z.im, so that consecutive elements are consecutive uint4s in every plane (coalesced
+// for the ladder's stores and for the normaliser's loads alike); Z occupies planes 5..7.
+FQ_DEV void store_proj(uint4* proj, u32 stride, u32 id, const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
+    u32 w[32];
+    store_xyz(w, X, Y, Z);
+    w[30] = w[31] = 0;
+#pragma unroll
+    for (int p = 0; p < PROJ_PLANES; p++) proj[(size_t)p * stride + id] = make_uint4(w[4 * p], w[4 * p + 1], w[4 * p + 2], w[4 * p + 3]);
+}
+FQ_DEV Fe2<1> load_proj_z(const uint4* proj, u32 stride, u32 id) {
+    uint4 a = proj[(size_t)5 * stride + id], b = proj[(size_t)6 * stride + id], c = proj[(size_t)7 * stride + id];
+    Fe2<1> z;
+    z.re.l[0] = a.x; z.re.l[1] = a.y; z.re.l[2] = a.z; z.re.l[3] = a.w; z.re.l[4] = b.x;
+    z.im.l[0] = b.y; z.im.l[1] = b.z; z.im.l[2] = b.w; z.im.l[3] = c.x; z.im.l[4] = c.y;
+    return z;
+}
+FQ_DEV void load_proj_xy(const uint4* proj, u32 stride, u32 id, Fe2<1>& X, Fe2<1>& Y) {
+    u32 w[20];
+#pragma unroll
+    for (int p = 0; p < 5; p++) {
+        uint4 v = proj[(size_t)p * stride + id];
+        w[4 * p] = v.x; w[4 * p + 1] = v.y; w[4 * p + 2] = v.z; w[4 * p + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) { X.re.l[i] = w[i]; X.im.l[i] = w[5 + i]; Y.re.l[i] = w[10 + i]; Y.im.l[i] = w[15 + i]; }
 }
 
 // T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                       curve4q.py:179-185
@@ -192,8 +224,10 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
 }
 
 // ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
-template <int ALGO, int SRC, bool DH>
+// DEFER (DH only): leave (X, Y, Z) in a.proj for normalize_kernel instead of inverting Z here.
+template <int ALGO, int SRC, bool DH, bool DEFER = false>
 __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
+    static_assert(!DEFER || DH, "only DH outputs are normalised");
     __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : 4];
     if (SRC == LDS) {
         for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
@@ -241,7 +275,12 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             constexpr bool CH = (FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN);
             Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(w, slot, R2_LIMBS);
         }
-        if (DH) {
+        if (DH && DEFER) {                                    // one inversion per K elements, later
+            if (live) {
+                store_proj(a.proj, a.proj_stride, id, Q.X, Q.Y, Q.Z);
+                a.status[id] = st;
+            }
+        } else if (DH) {
             Fe2<1> ax, ay;
             r1_to_affine(Q, ax, ay);
             u64 o[8];
@@ -274,7 +313,8 @@ constexpr int COMB_LDS_U32 = COMB_ENTRY_U32 + 4;              // padded stride i
 
 #if FQ_CHAIN   // only fourq_chain.hip launches it
 // [m]B, affine, from the comb: 9 doublings + 49 mixed additions per element
-__global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
+template <bool DEFER>
+__global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
     __shared__ __attribute__((aligned(16))) u32 lds[COMB_POINTS * COMB_LDS_U32];
     for (int i = threadIdx.x; i < COMB_POINTS * COMB_ENTRY_U32; i += BLOCK)
         lds[(i / COMB_ENTRY_U32) * COMB_LDS_U32 + (i % COMB_ENTRY_U32)] = comb_limbs[i];
@@ -301,6 +341,13 @@ __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, cons
                 Q = add_affine_table(Q, entry, neg);
             }
         }
+        if (DEFER) {                                          // deferred normalisation, see normalize_kernel
+            if (live) {
+                store_proj(proj, proj_stride, id, fe2_carry(fe2_cneg(Q.X, c.negate)), Q.Y, Q.Z);   // even scalar: -(x, y) = (-x, y)
+                status[id] = FOURQ_DH_OK;
+            }
+            continue;
+        }
         Fe2<1> ax, ay;
         r1_to_affine(Q, ax, ay);
         ax = fe2_carry(fe2_cneg(ax, c.negate));               // even scalar: [k]B = -[N - k]B, -(x, y) = (-x, y)
@@ -319,6 +366,61 @@ __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, cons
     }
 }
 
+// R1toAffine for a whole batch with one GF(p) inversion per K elements (Montgomery's trick; SURVEY 8f row 4,
+// curve4q.py:103-106, fields.py:66-106, :193-199).  Lane t owns elements t, t + T, ..., t + (K-1)T with
+// T = ceil(n / K): it multiplies up the norms |Z|^2, inverts the product once and peels the individual inverses
+// off on the way back.  Elements already rejected (status != 0) and the ragged tail contribute a 1.  The affine
+// result is canonical, hence identical to the per-element inversion.  Z != 0 for every point of the curve (the
+// addition law is complete), so a product is zero only for rejected elements, which are masked.
+template <int K>
+__global__ __launch_bounds__(BLOCK) void normalize_kernel(const uint4* proj, u32 stride, u64* out, uint8_t* status, u32 n) {
+    const u32 T = (n + K - 1) / K;
+    const u32 t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    Fe<1> one;
+    one.l[0] = 1; one.l[1] = one.l[2] = one.l[3] = one.l[4] = 0;
+    Fe2<1> z[K];
+    uint8_t st[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {                     // all loads first: the lane's K elements are K separate cache lines
+        const u32 id = t + (u32)j * T, at = id < n ? id : t;
+        z[j] = load_proj_z(proj, stride, at);
+        st[j] = id < n ? status[at] : (uint8_t)FOURQ_DH_NOT_ON_CURVE;
+    }
+    Fe<1> nz[K], pre[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        Fe<1> norm = fe_carry(fe_add(fe_sqr(z[j].re), fe_sqr(z[j].im)));
+        nz[j] = fe_select(st[j] == FOURQ_DH_OK ? ~0u : 0u, norm, one);
+        if (j == 0) pre[0] = nz[0]; else pre[j] = fe_mul(pre[j - 1], nz[j]);
+    }
+    Fe<1> inv = fe_inv(pre[K - 1]);
+#pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        const u32 id = t + (u32)j * T, at = id < n ? id : t;
+        Fe2<1> X, Y, zi;
+        load_proj_xy(proj, stride, at, X, Y);
+        Fe<1> ninv = inv;                                              // 1 / |Z_j|^2
+        if (j > 0) { ninv = fe_mul(inv, pre[j - 1]); inv = fe_mul(inv, nz[j]); }
+        zi.re = fe_mul(ninv, z[j].re);                                 // conj(Z) / |Z|^2     fields.py:193-199
+        zi.im = fe_mul(ninv, fe_neg(z[j].im));
+        u64 o[8];
+        store_fe2(o, fe2_mul(X, zi));
+        store_fe2(o + 4, fe2_mul(Y, zi));
+        uint8_t s = st[j];
+        if (s == FOURQ_DH_OK && (o[0] | o[1] | o[2] | o[3] | o[5] | o[6] | o[7]) == 0 && o[4] == 1) s = FOURQ_DH_NEUTRAL;   // curve4q.py:459-460
+        if (id < n) {
+            uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)id);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u64 lo = s ? 0 : o[2 * k], hi = s ? 0 : o[2 * k + 1];
+                dst[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+            }
+            status[id] = s;
+        }
+    }
+}
+
 #endif
 
 }  // namespace
@@ -326,6 +428,7 @@ __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, cons
 // launchers implemented in fourq_chain.hip (FQ_CHAIN=1 code objects)
 int chain_launch_ladder(int algo, int src, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int chain_launch_prep(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
-int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n);
+int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n);
+int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
 
 }  // namespace fq

@@ -109,7 +109,9 @@ int fourq_mul_endo_mixed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, cons
 /* ---- Diffie-Hellman: DH_core(m_i, P_i, mul, table) curve4q.py:446-462 --------------------------
  * table == NULL: variable base (the table is built from [392]P_i); otherwise `table` (host pointer)
  * is used for every element exactly as the reference does (it ignores the point, curve4q.py:209, :426).
- * status[i]: FOURQ_DH_*; out_affine[i] is all zero when status[i] != 0. */
+ * status[i]: FOURQ_DH_*; out_affine[i] is all zero when status[i] != 0.
+ * Large batches share one GFp.inv (fields.py:66-106) among up to eight elements of R1toAffine (curve4q.py:103-106;
+ * Montgomery's trick); the affine result is canonical and therefore unchanged. */
 int fourq_dh_endo_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,
                         uint64_t *out_affine, uint8_t *status, size_t n);
 int fourq_dh_windowed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,

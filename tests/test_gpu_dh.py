@@ -145,3 +145,55 @@ def test_reference_self_test_sequence_on_the_gpu():
     assert text.count("[PASS]") >= 45
     for label in ("double", "addition", "mul-windowed", "mul-endo", "phi", "psi", "encode", "decode", "DH-endo-symm", "DH-reject-392-torsion"):
         assert "[PASS] %s\n" % label in text
+
+
+@pytest.mark.parametrize("group", [0, 2, 4, 8])
+@pytest.mark.parametrize("n", [1, 7, 1000, 2049])
+def test_batched_normalisation_groups(group, n, monkeypatch, golden):
+    """R1toAffine with one inversion per `group` elements (Montgomery's trick): FOURQ_NORM_K forces the
+    group size that large batches pick by themselves and FOURQ_SPLIT_MIN=512 sends n >= 512 down the prep + ladder route
+    (which always defers; group 0 there means one inversion per element in normalize_kernel).  Rejected elements
+    (off-curve, 392-torsion) sit inside the groups; every output and status must equal the C oracle's."""
+    from fourq_amd import Engine
+    monkeypatch.setenv("FOURQ_NORM_K", str(group))
+    monkeypatch.setenv("FOURQ_SPLIT_MIN", "512")
+    e = Engine(0)
+    try:
+        s = seeded_scalars(4242 + n, n)
+        g = np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0)
+        t392 = e.table_endo(codec.pack_point(o.MUL_endo(392, o.AffineToR1(*G))))
+        pts, st = e.dh_endo(seeded_scalars(4343 + n, n), g, t392)              # fixed-base DH (LDS ladder)
+        want, wst = oc.dh(oc.ENDO, seeded_scalars(4343 + n, n), g)
+        assert not st.any() and np.array_equal(pts, want)
+        pts = pts.copy()
+        pts[3::7] = codec.pack_point(unhex(golden("kat.json", raw=True)["P392"]))   # -> neutral
+        pts[5::11, 0] ^= np.uint64(1)                                                # -> not on curve
+        for kind, fn in ((oc.ENDO, e.dh_endo), (oc.WINDOWED, e.dh_windowed)):       # variable base
+            want, wst = oc.dh(kind, s, pts)
+            got, gst = fn(s, pts)
+            assert np.array_equal(gst, wst) and np.array_equal(got, want), (kind, group, n)
+        comb = e.comb_table(codec.pack_point(o.MUL_endo(392, o.AffineToR1(*G))))
+        s[::13] = 0                                                              # [0]B -> neutral inside a group
+        want, wst = oc.dh(oc.ENDO, s, g)
+        got, gst = e.comb_mul(s, comb)
+        assert np.array_equal(gst, wst) and np.array_equal(got, want)
+    finally:
+        e.close()
+
+
+def test_batched_normalisation_large_batches_pick_a_group(eng):
+    """2^18 + 3 elements is >= 4 resident generations of fused lanes: group 4 by default.  Fixed-base DH, variable-base DH
+    and the comb must all agree with the C oracle on a slice and with each other in full."""
+    n = (1 << 18) + 3
+    s = seeded_scalars(9191, n)
+    g = np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0)
+    g392 = codec.pack_point(o.MUL_endo(392, o.AffineToR1(*G)))
+    fixed, st = eng.dh_endo(s, g, eng.table_endo(g392))
+    assert not st.any()
+    comb, st = eng.comb_mul(s, eng.comb_table(g392))
+    assert not st.any() and np.array_equal(comb, fixed)
+    var, st = eng.dh_endo(s, g)
+    assert not st.any() and np.array_equal(var, fixed)
+    for lo in (0, n - 2048):
+        want, wst = oc.dh(oc.ENDO, s[lo:lo + 2048], g[:2048])
+        assert np.array_equal(fixed[lo:lo + 2048], want)
