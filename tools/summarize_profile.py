@@ -18,7 +18,7 @@ src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERNEL = sys.argv[3] if len(sys.argv) > 3 else "ladder_kernel<0, false, false>"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "ladder_kernel<0, 0, false, false>"
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
