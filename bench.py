@@ -146,7 +146,7 @@ WORKLOADS = {
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
                       "(first half fixed-base through the 80-point comb of [392]G, same affine outputs as with table_endo([392]G); "
                       "second half variable-base); affine in/out"),
-    "cfg5": dict(batch=1 << 17, bytes=(192 + 352) // 2, mads=(83_300 + 97_600) // 2, kernel="ladder_kernel<ENDO, LDS> + ladder_kernel<ENDO, FUSED> over a device-side partition",
+    "cfg5": dict(batch=1 << 17, bytes=(192 + 352) // 2, mads=(83_300 + 97_600) // 2, kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer",
                  text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo"),
 }
 

@@ -43,12 +43,46 @@ __global__ void table_build_kernel(int algo, const u64* p_r1, u32* scratch, u64*
     if (algo == ENDO) build_table_endo(P, scratch); else build_table_windowed(P, scratch);
     for (int k = 0; k < 8; k++) store_r2_packed(packed + 16 * k, load_r2_limbs(scratch + k * R2_LIMBS));
 }
-// stable partition of element ids by flag for mixed batches: idx[0..nf) fixed, idx[n-nv..n) variable
-__global__ void partition_kernel(const uint8_t* flags, u32 n, u32* idx, u32* counters) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flags[i] == 0) idx[atomicAdd(&counters[0], 1u)] = i;
-    else idx[n - 1 - atomicAdd(&counters[1], 1u)] = i;
+// Mixed batches: compacts the ids of the variable-base elements of one round (flags[i] != 0) into var_list (any
+// order) and records, per element of the round, which scratch slot holds its table: slot_of[i] = rank in var_list,
+// or ~0 for a fixed-base element (shared table).  Sixteen flags per lane, a block scan in LDS and one atomic per
+// 4 096 elements; one atomic per element (or per wave) serialises on the counter.
+constexpr int PART_PER_LANE = 16;
+__global__ __launch_bounds__(BLOCK) void partition_kernel(const uint8_t* flags, u32 n, u32 first_id, u32* var_list, u32* slot_of, u32* counter) {
+    __shared__ u32 scan[BLOCK], base;
+    const u32 t = threadIdx.x;
+    const u32 first = (blockIdx.x * BLOCK + t) * PART_PER_LANE;
+    const u32 valid = first < n ? (n - first < (u32)PART_PER_LANE ? n - first : (u32)PART_PER_LANE) : 0u;
+    uint8_t f[PART_PER_LANE];
+    if (valid == PART_PER_LANE && (reinterpret_cast<uintptr_t>(flags) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(flags + first);
+        const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int k = 0; k < PART_PER_LANE; k++) f[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+    } else {
+#pragma unroll
+        for (int k = 0; k < PART_PER_LANE; k++) f[k] = (u32)k < valid ? flags[first + k] : (uint8_t)0;
+    }
+    u32 mine = 0;
+#pragma unroll
+    for (int k = 0; k < PART_PER_LANE; k++) mine += ((u32)k < valid && f[k] != 0) ? 1u : 0u;
+    scan[t] = mine;
+    __syncthreads();
+    for (u32 off = 1; off < BLOCK; off <<= 1) {           // inclusive scan
+        const u32 below = t >= off ? scan[t - off] : 0u;
+        __syncthreads();
+        scan[t] += below;
+        __syncthreads();
+    }
+    if (t == BLOCK - 1) base = atomicAdd(counter, scan[t]);
+    __syncthreads();
+    u32 rank = base + scan[t] - mine;
+#pragma unroll
+    for (int k = 0; k < PART_PER_LANE; k++) {
+        if ((u32)k >= valid) break;
+        if (f[k] != 0) { var_list[rank] = first_id + first + k; slot_of[first + k] = rank++; }
+        else slot_of[first + k] = ~0u;
+    }
 }
 
 // One lane per table entry: P[j][u] = [2^(e j) (1 + u0 2^d + u1 2^2d + u2 2^3d + u3 2^4d)] B by the ordinary
@@ -229,11 +263,9 @@ struct fourq_ctx {
     u64* table_packed = nullptr;   // 128 words
     u32* comb_limbs = nullptr;     // 80 x 36 working limbs of the staged comb table
     u64* comb_packed = nullptr;    // 80 x 12 words
-    u32* part_counters = nullptr;  // 2
-    u32* part_index = nullptr;     // element ids of a mixed batch, partitioned by flag
-    size_t part_capacity = 0;
-    hipStream_t aux_stream = nullptr;   // the variable-base half of a mixed batch runs beside the fixed-base half
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    u32* part_counter = nullptr;   // mixed batches: number of variable-base elements of the current round (device side)
+    u32* part_list = nullptr;      // their ids, split_chunk entries
+    u32* part_slot = nullptr;      // per element of the round: scratch slot of its table, ~0 = shared table
     uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
     size_t proj_capacity = 0;
     int norm_k = -1;               // FOURQ_NORM_K: 0 = always invert per element, 2/4/8 = always batch; -1 = by batch size
@@ -471,12 +503,11 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (hipMalloc(&c->scratch, slots * SLOT_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
-        if (hipMalloc(&c->part_counters, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->part_counter, sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->part_list, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->part_slot, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->comb_limbs, COMB_POINTS * COMB_ENTRY_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->comb_packed, FOURQ_COMB_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
-        if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
-        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
-        if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
     } while (0);
     if (rc) { fourq_ctx_destroy(c); return rc; }
     *out = c;
@@ -491,13 +522,11 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->proj) (void)hipFree(c->proj);
     if (c->table_limbs) (void)hipFree(c->table_limbs);
     if (c->table_packed) (void)hipFree(c->table_packed);
-    if (c->part_counters) (void)hipFree(c->part_counters);
+    if (c->part_counter) (void)hipFree(c->part_counter);
+    if (c->part_list) (void)hipFree(c->part_list);
+    if (c->part_slot) (void)hipFree(c->part_slot);
     if (c->comb_limbs) (void)hipFree(c->comb_limbs);
     if (c->comb_packed) (void)hipFree(c->comb_packed);
-    if (c->part_index) (void)hipFree(c->part_index);
-    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stage) (void)hipFree(c->stage);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -581,35 +610,29 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     if (!c || !s || !p || !flags || !table || !o || n > 0xffffffffu) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    if (n > c->part_capacity) {                       // grows only: steady-state calls allocate nothing
-        if (c->part_index) { HIP_TRY(c, hipFree(c->part_index)); c->part_index = nullptr; c->part_capacity = 0; }
-        HIP_TRY(c, hipMalloc(&c->part_index, n * sizeof(u32)));
-        c->part_capacity = n;
-    }
     int rc = stage_table(c, table);
     if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->part_counters, 0, 2 * sizeof(u32), c->stream));
-    hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, flags, (u32)n, c->part_index, c->part_counters);
-    HIP_TRY(c, hipGetLastError());
-    // fixed-base ids fill part_index from the front, variable-base ids from the back; both counts stay on the device.
-    // The two halves are independent: the variable-base half runs on the auxiliary stream beside the fixed-base half.
-    LadderArgs a = {};
-    a.scalars = s; a.points = p; a.out = o; a.index = c->part_index; a.n = (u32)n;
-    a.scratch = c->scratch; a.table = c->table_limbs;
-    size_t blocks = (n + BLOCK - 1) / BLOCK;
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    LadderArgs av = a;
-    av.n_dev = c->part_counters + 1; av.rev = (u32)n;
-    unsigned gv = (unsigned)(blocks < c->lanes / BLOCK ? blocks : c->lanes / BLOCK);
-    hipLaunchKernelGGL((ladder_kernel<ENDO, FUSED, false>), dim3(gv), dim3(BLOCK), 0, c->aux_stream, av);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
-    LadderArgs af = a;
-    af.n_dev = c->part_counters;
-    unsigned gf = (unsigned)(blocks < c->lanes_w4 / BLOCK ? blocks : c->lanes_w4 / BLOCK);
-    HIPRC_TRY(c, chain_launch_ladder(ENDO, LDS, false, gf, c->stream, af));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    // Rounds of up to split_chunk elements.  Per round: compact the variable-base ids (count stays on the device),
+    // build their tables into scratch slots (prep_kernel over the compacted list), then ONE ladder launch over all
+    // elements of the round in their natural order: each lane reads its table through a pointer -- its own slot or
+    // the shared fixed-base table -- so fixed and variable elements share wavefronts without divergence.
+    const size_t per_block = (size_t)BLOCK * PART_PER_LANE;
+    for (size_t off = 0; off < n; off += c->split_chunk) {
+        const u32 m = (u32)(n - off < c->split_chunk ? n - off : c->split_chunk);
+        HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, sizeof(u32), c->stream));
+        hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((m + per_block - 1) / per_block)), dim3(BLOCK), 0, c->stream,
+                           flags + off, m, (u32)off, c->part_list, c->part_slot, c->part_counter);
+        HIP_TRY(c, hipGetLastError());
+        LadderArgs a = {};
+        a.scalars = s; a.points = p; a.out = o; a.n = m;
+        a.scratch = c->scratch; a.table = c->table_limbs;
+        LadderArgs ap = a;
+        ap.index = c->part_list; ap.n_dev = c->part_counter;
+        HIPRC_TRY(c, chain_launch_prep(ENDO, false, (m + BLOCK - 1) / BLOCK, c->stream, ap));
+        a.base = (u32)off; a.slot_of = c->part_slot;
+        rc = launch_ladder<ENDO, PREBUILT, false>(c, a);
+        if (rc) return rc;
+    }
     return FOURQ_OK;
 }
 FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint8_t* flags,
@@ -624,11 +647,6 @@ FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uin
     HIP_TRY(c, hipMemcpyAsync(base, s, sb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(base + sb, p, pb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(base + sb + pb + ob, flags, n, hipMemcpyHostToDevice, c->stream));
-    if (n > c->part_capacity) {                       // allocate the index list before staging: growing it must not free `stage`
-        if (c->part_index) { HIP_TRY(c, hipFree(c->part_index)); c->part_index = nullptr; c->part_capacity = 0; }
-        HIP_TRY(c, hipMalloc(&c->part_index, n * sizeof(u32)));
-        c->part_capacity = n;
-    }
     rc = fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)base, (const uint64_t*)(base + sb), (const uint8_t*)(base + sb + pb + ob),
                                         table, (uint64_t*)(base + sb + pb), n);
     if (rc) return rc;

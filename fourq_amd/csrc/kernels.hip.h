@@ -34,10 +34,10 @@ struct LadderArgs {
     const u64* points;     // variable base: n x 20 (R1) ; DH: n x 8 (affine) ; else unused
     u64* out;              // n x 20 (R1) or n x 8 (affine, DH)
     uint8_t* status;       // DH only
-    const u32* index;      // optional: element ids to process (mixed batches); NULL = identity
+    const u32* index;      // optional: element ids to process (prep_kernel over the variable-base ids of a mixed batch); NULL = identity
     u32 base;              // first position of this launch (chunked large batches)
     const u32* n_dev;      // optional: element count read on the device (mixed batches: no host round trip)
-    u32 rev;               // non-zero: ids are index[rev - 1 - pos] (the variable-base half of a partition, filled from the end)
+    const u32* slot_of;    // PREBUILT, optional (mixed batches): per position, the scratch slot of its table or ~0 = `table`
     const u32* table;      // fixed base: 8 x 48 working limbs (global), staged to LDS
     u32* scratch;          // variable base: SLOT_U32 per resident lane (FUSED) or per position of the chunk (PREBUILT)
     uint4* proj;           // DH, optional: PROJ_PLANES x proj_stride; non-NULL selects the kernels that leave (X, Y, Z)
@@ -209,7 +209,7 @@ namespace {   // kernels: one private copy per translation unit (their code obje
 template <int ALGO, bool DH>
 __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
     const u32 pos = blockIdx.x * BLOCK + threadIdx.x;
-    if (pos >= a.n) return;
+    if (pos >= (a.n_dev ? *a.n_dev : a.n)) return;
     const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
     R1 P;
     if (DH) {
@@ -242,10 +242,15 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
     for (u32 it = lane_slot; it < n_round; it += lanes) {
         const bool live = it < n;
         const u32 pos = live ? it : n - 1;                // idle tail lanes redo the last element, store nothing
-        const u32 id = a.index ? a.index[a.rev ? a.rev - 1 - pos : a.base + pos] : a.base + pos;
+        const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
         u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * SLOT_U32;
+        const u32* tbl = slot;
+        if (SRC == PREBUILT && a.slot_of) {                              // mixed batch: own table or the shared one
+            const u32 own = a.slot_of[pos];
+            tbl = own == ~0u ? a.table : a.scratch + (size_t)own * SLOT_U32;
+        }
 
         uint8_t st = FOURQ_DH_OK;
         if (SRC == PREBUILT) {
@@ -269,11 +274,11 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             decompose(m, v);
             EndoDigits e = recode(v);
             constexpr bool CH = (FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN);
-            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(e, slot, R2_LIMBS);
+            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(e, tbl, R2_LIMBS);
         } else {
             WinScalar w = win_reduce(m);
             constexpr bool CH = (FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN);
-            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(w, slot, R2_LIMBS);
+            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(w, tbl, R2_LIMBS);
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
             if (live) {
