@@ -134,7 +134,7 @@ def edge_case_check(eng):
 # per-workload constants: algorithmic bytes per unit and v_mad_u64_u32 issued per unit by this
 # implementation, counted from the formulas: GF(p^2) M = 100, S = 50; DBL = 3M+4S = 500,
 # ADD = 8M = 800; ladder step 1 300 (x64 endo, 4 DBL + ADD = 2 800 x62 windowed); table_endo 14 300;
-# DH extras (membership, x392, inversion) 8 600; comb 9 DBL + 49 mixed ADD (7M) + inversion = 37 000; at cfg4's size
+# DH extras (membership, x392, inversion) 8 600; comb 9 DBL + 49 mixed ADD (7M) = 38 800 + inversion 2 500; at cfg4's size
 # eight elements share one inversion (normalize_kernel<8>): -1 800 per DH_core
 WORKLOADS = {
     "cfg2": dict(batch=1 << 16, bytes=32 + 160 + 160, mads=97_600, kernel="ladder_kernel<ENDO, FUSED>",
@@ -142,7 +142,7 @@ WORKLOADS = {
                       "projective N-torsion points, raw R1 in/out resident in HBM"),
     "cfg3": dict(batch=1 << 20, bytes=32 + 160, mads=173_600, kernel="ladder_kernel<WINDOWED, LDS>",
                  text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
-    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=35_200 + 97_600 + 6_800, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
+    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=39_400 + 97_600 + 6_800, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
                       "(first half fixed-base through the 80-point comb of [392]G, same affine outputs as with table_endo([392]G); "
                       "second half variable-base); affine in/out"),
