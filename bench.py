@@ -102,6 +102,38 @@ def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
             "per_core": round(per_core / busy, 1)}
 
 
+def c_port_baseline(workload, scalars_h, second_h, points_h, table_h, flags_h, expected_words):
+    """The C restatement (oracle/fourq_oracle.c, OpenMP) over the WHOLE timed batch: a second parity gate on every
+    output and, for context, its rate on the same host cores."""
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_c as oc
+    from fourq_amd import codec, constants
+    oc.lib()
+    t0 = time.perf_counter()
+    if workload == "cfg2":
+        got = oc.mul(oc.ENDO, scalars_h, points_h)
+    elif workload == "cfg3":
+        got = oc.mul(oc.WINDOWED, scalars_h, None, table_h)
+    elif workload == "cfg4":
+        g = np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), len(scalars_h), axis=0)
+        mid, st1 = oc.dh(oc.ENDO, second_h, g)
+        got, st2 = oc.dh(oc.ENDO, scalars_h, mid)
+        if st1.any() or st2.any():
+            raise SystemExit("cfg4: unexpected DH failure status in the C oracle")
+    else:
+        fixed = oc.mul(oc.ENDO, scalars_h, None, table_h)
+        var = oc.mul(oc.ENDO, scalars_h, points_h)
+        got = np.where(flags_h.reshape(-1, 1) != 0, var, fixed)
+    dt = time.perf_counter() - t0
+    if not np.array_equal(got, expected_words):
+        raise SystemExit("PARITY FAILURE: GPU result differs from the C oracle on the full batch (%s)" % workload)
+    units = len(scalars_h) * (2 if workload == "cfg5" else 1)     # cfg5 evaluates both variants of every element
+    return {"value": round(units / dt, 1), "unit": "scalar-mults/s", "threads": oc.num_threads(), "cores": host_cores(), "kind": "port",
+            "sample": "whole batch (%d units) via oracle/fourq_oracle.c, every output compared bit-exact with the GPU's" % len(scalars_h)}
+
+
 def edge_case_check(eng):
     """SURVEY.md 8d: every run carries an edge-case mini-batch -- scalars {0,1,2,N-1,N,N+1,2N,2^255,2^256-1}
     on G and -G through MUL_endo, MUL_windowed and DH_endo, bit-exact against the Python oracle (part of the
@@ -302,6 +334,8 @@ def main():
                 pts = codec.unpack_points(points.cpu().numpy().view(np.uint64))
                 items = [(m, P if f else None) for m, P, f in zip(ms, pts, flags_h)]
                 line["cpu_baseline"] = cpu_baseline("mixed", items, codec.unpack_table(extra_h), expected, "50/50 fixed/variable MUL_endo")
+            line["cpu_baseline"]["c_restatement"] = c_port_baseline(
+                args.workload, scalars_h, second_h, points.cpu().numpy().view(np.uint64), extra_h, flags_h if args.workload == "cfg5" else None, out_h)
             line["cpu_baseline"]["sample"] += "; plus %d edge-case scalar/point pairs (0, 1, 2, N-1, N, N+1, 2N, 2^255, 2^256-1 on +-G), exact" % edge_case_check(eng)
         print(json.dumps(line), flush=True)
     eng.close()

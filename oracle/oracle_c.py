@@ -1,4 +1,5 @@
-"""ctypes access to the C oracle (oracle/fourq_oracle.c) for the tests.  TEST INFRASTRUCTURE."""
+"""ctypes access to the C oracle (oracle/fourq_oracle.c) for the tests and for the cpu_baseline leg of bench.py.
+TEST INFRASTRUCTURE: nothing under fourq_amd/ may import this."""
 import ctypes
 import os
 import subprocess
@@ -30,6 +31,7 @@ def lib():
         _lib.fqo_mul_batch.argtypes = [i, vp, vp, vp, vp, sz]
         _lib.fqo_dh_batch.argtypes = [i, vp, vp, vp, vp, vp, sz]
         _lib.fqo_decompose_batch.argtypes = [vp, vp, sz]
+        _lib.fqo_num_threads.restype = ctypes.c_int
         for f in (_lib.fqo_table_windowed, _lib.fqo_table_endo, _lib.fqo_mul_batch, _lib.fqo_dh_batch, _lib.fqo_decompose_batch):
             f.restype = None
     return _lib
@@ -77,3 +79,7 @@ def decompose(scalars):
     out = np.empty_like(s)
     lib().fqo_decompose_batch(_p(s), _p(out), len(s))
     return out
+
+
+def num_threads():
+    return int(lib().fqo_num_threads())
