@@ -39,6 +39,11 @@ with Engine(0) as eng:
         t0 = time.time(); a = gpu(); t1 = time.time(); b = cpu(); t2 = time.time()
         print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  C oracle %.1fs  identical=%s" % (name, LG, t1 - t0, t2 - t1, np.array_equal(a, b)), flush=True)
         assert np.array_equal(a, b)
+    flags = (np.frombuffer(random.Random(5).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
+    t0 = time.time(); a = eng.mul_endo_mixed(s, pts, flags, te); t1 = time.time()
+    b = np.where(flags.reshape(-1, 1) != 0, oc.mul(oc.ENDO, s, pts), oc.mul(oc.ENDO, s, None, te))
+    print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  identical=%s" % ("MUL_endo mixed 50/50", LG, t1 - t0, np.array_equal(a, b)), flush=True)
+    assert np.array_equal(a, b)
     aff, st = eng.dh_endo(scalars(3), np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0), te if False else None)
     assert not st.any()
     for name, gpu, cpu in (("DH_endo variable base", lambda: eng.dh_endo(s, aff), lambda: oc.dh(oc.ENDO, s, aff)),
