@@ -21,6 +21,14 @@ from .engine import default_engine
 from .fields import GFp, GFp2  # noqa: F401
 
 p1271 = P127
+# the reference's remaining module-level constants under their own names (curve4q.py:240-256, :326-337)
+from .constants import ctau, ctaudual  # noqa: E402,F401
+from . import constants as _k  # noqa: E402
+cphi0, cphi1, cphi2, cphi3, cphi4, cphi5, cphi6, cphi7, cphi8, cphi9 = _k.cphi
+cpsi1, cpsi2, cpsi3, cpsi4 = (_k.cpsi[i] for i in (1, 2, 3, 4))
+b1, b2, b3, b4 = (list(row) for row in _k.BASIS)
+L1, L2, L3, L4 = _k.ELL
+c, cp = list(_k.OFFSET_C), list(_k.OFFSET_CP)
 
 _MSG = {1: "Point not on curve", 2: "DH computation resulted in neutral point"}   # curve4q.py:448, :460
 

@@ -92,3 +92,23 @@ def test_wire_random(ref):
         except Exception as exc:
             got = (type(exc).__name__, str(exc))
         assert got == want
+
+
+def test_mirror_module_has_every_public_name_of_the_reference(ref):
+    """A user who swaps `import curve4q` for `from fourq_amd import curve4q` must find every module-level name
+    (functions and constants; the reference's own test functions and its `getrandbits` import aside), and every
+    constant must hold the same value.  Importing the mirror needs no GPU."""
+    f, c = ref
+    from fourq_amd import curve4q as m
+    from fourq_amd import fields as mf
+    skip = {"getrandbits", "test"} | {n for n in dir(c) if n.startswith("test_")}
+    public = [n for n in dir(c) if not n.startswith("_") and n not in skip]
+    assert [n for n in public if not hasattr(m, n)] == []
+    for n in public:
+        v = getattr(c, n)
+        if isinstance(v, (int, tuple, list)):
+            assert getattr(m, n) == v, n
+    for cls in ("GFp", "GFp2"):
+        want = [n for n in dir(getattr(f, cls)) if not n.startswith("_") and n not in ("A", "S", "M", "I", "ctr", "ctr_reset", "ctr_enabled")]   # op counters: not reproduced
+        have = dir(getattr(mf, cls))
+        assert [n for n in want if n not in have] == [], cls
