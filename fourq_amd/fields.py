@@ -99,5 +99,18 @@ class GFp2:
         return _fp2("FP2_INV", a)
 
     @staticmethod
+    def invsqrt(a):                                    # fields.py:202-230 (unused by the reference; restated as written,
+        if a[1] == 0:                                  # including `== -1` tests that can never hold)
+            t = GFp.invsqrt(a[0])
+            return (t, 0) if GFp.mul(a[0], GFp.sqr(t)) == 1 else (0, t)
+        n = GFp.add(GFp.sqr(a[0]), GFp.sqr(a[1]))
+        s = GFp.invsqrt(n)
+        c = GFp.mul(n, s)
+        delta = GFp.mul(GFp.add(a[0], c), GFp.half)
+        g = GFp.invsqrt(delta)
+        h = GFp.mul(delta, g)
+        return (GFp.mul(h, s), GFp.neg(GFp.mul(GFp.mul(GFp.mul(a[1], s), g), GFp.half)))
+
+    @staticmethod
     def select(c, x, y):                               # fields.py:237
         return x if c == 1 else y

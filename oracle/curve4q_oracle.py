@@ -122,6 +122,22 @@ def f2_select(c, x, y):  # fields.py:237-238
     return (fp_select(c, x[0], y[0]), fp_select(c, x[1], y[1]))
 
 
+def f2_invsqrt(a):  # fields.py:202-230, off the hot path and unused by the reference itself
+    """Behaviour restated as written: the `== -1` tests (fields.py:217, :223) can never hold for residues in
+    [0, p), so non-squares are not rejected and the second root choice is never taken."""
+    if a[1] == 0:
+        t = fp_invsqrt(a[0])
+        return (t, 0) if fp_mul(a[0], fp_sqr(t)) == 1 else (0, t)
+    n = fp_add(fp_sqr(a[0]), fp_sqr(a[1]))
+    s = fp_invsqrt(n)
+    c = fp_mul(n, s)
+    half = 1 << 126
+    delta = fp_mul(fp_add(a[0], c), half)
+    g = fp_invsqrt(delta)
+    h = fp_mul(delta, g)
+    return (fp_mul(h, s), fp_neg(fp_mul(fp_mul(fp_mul(a[1], s), g), half)))
+
+
 class GFp:
     """Reference-shaped namespace (fields.py:9) so tests read like the reference's own."""
 
@@ -135,7 +151,7 @@ class GFp2:
 
     zero, one, two = F2_ZERO, F2_ONE, F2_TWO
     add, sub, mul, sqr, neg = map(staticmethod, (f2_add, f2_sub, f2_mul, f2_sqr, f2_neg))
-    conj, inv, select = map(staticmethod, (f2_conj, f2_inv, f2_select))
+    conj, inv, select, invsqrt = map(staticmethod, (f2_conj, f2_inv, f2_select, f2_invsqrt))
 
 
 # ---------------------------------------------------------------------------------------------

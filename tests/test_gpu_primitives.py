@@ -159,3 +159,25 @@ def test_recode_random(eng):
         sgn, ind = o.recode_windowed(m)
         raw = row.tobytes()[:63]
         assert [b >> 3 for b in raw] == sgn and [b & 7 for b in raw] == ind
+
+
+def test_reference_shaped_field_namespaces():
+    """fourq_amd.fields.GFp / GFp2 (the mirror a module swap lands on) against the oracle, one call per function,
+    GFp2.invsqrt (fields.py:202-230, composed on the host from GFp primitives) included."""
+    import random
+    from fourq_amd.fields import GFp, GFp2
+    rng = random.Random(99)
+    p = o.P127 if hasattr(o, "P127") else (1 << 127) - 1
+    for _ in range(6):
+        x, y = rng.getrandbits(127) % p, rng.getrandbits(127) % p
+        a, b = (x, y), (rng.getrandbits(127) % p, rng.getrandbits(127) % p)
+        for name in ("add", "sub", "mul"):
+            assert getattr(GFp, name)(x, y) == getattr(o.GFp, name)(x, y)
+            assert getattr(GFp2, name)(a, b) == getattr(o.GFp2, name)(a, b)
+        for name in ("sqr", "neg", "inv", "invsqrt"):
+            assert getattr(GFp, name)(x) == getattr(o.GFp, name)(x)
+        for name in ("sqr", "neg", "conj", "inv", "invsqrt"):
+            assert getattr(GFp2, name)(a) == getattr(o.GFp2, name)(a), name
+        assert GFp2.invsqrt((x, 0)) == o.GFp2.invsqrt((x, 0))
+        assert GFp.select(1, x, y) == x and GFp2.select(0, a, b) == b
+    assert (GFp2.zero, GFp2.one, GFp2.two, GFp.half) == ((0, 0), (1, 0), (2, 0), 1 << 126)

@@ -112,3 +112,13 @@ def test_mirror_module_has_every_public_name_of_the_reference(ref):
         want = [n for n in dir(getattr(f, cls)) if not n.startswith("_") and n not in ("A", "S", "M", "I", "ctr", "ctr_reset", "ctr_enabled")]   # op counters: not reproduced
         have = dir(getattr(mf, cls))
         assert [n for n in want if n not in have] == [], cls
+
+
+def test_gfp2_invsqrt_as_written(ref):
+    """GFp2.invsqrt (fields.py:202-230) is dead code in the reference; the restatement follows it to the letter."""
+    f, _ = ref
+    rng = random.Random(15)
+    cases = [(rng.getrandbits(127) % f.p1271, rng.getrandbits(127) % f.p1271) for _ in range(40)]
+    cases += [(rng.getrandbits(127) % f.p1271, 0) for _ in range(20)] + [(4, 0), (1, 0), (2, 0)]
+    for a in cases:
+        assert o.GFp2.invsqrt(a) == f.GFp2.invsqrt(a), a
