@@ -300,6 +300,9 @@ int ensure_stage(fourq_ctx* c, size_t bytes) {
     return FOURQ_OK;
 }
 
+// device arrays are accessed as 16-byte vectors: every array pointer of the _dev API must be 16-byte aligned
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 #define HIPRC_TRY(c, expr) do { hipError_t e_ = (hipError_t)(expr); if (e_ != hipSuccess) return fail((c), e_, #expr); } while (0)
 
 template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs a) {
@@ -370,6 +373,7 @@ int stage_table(fourq_ctx* c, const uint64_t* table_host) {
 int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
             const u32* index, size_t n) {
     if (!c || !scalars || !out || (!points && !table) || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!aligned16(scalars) || !aligned16(out) || !aligned16(points)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     LadderArgs a = {};
@@ -383,6 +387,7 @@ int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
 int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
            uint8_t* status, size_t n) {
     if (!c || !scalars || !points || !out || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!aligned16(scalars) || !aligned16(points) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     LadderArgs a = {};
@@ -617,6 +622,7 @@ FQ_API int fourq_mul_windowed_fixed_batch_dev(fourq_ctx* c, const uint64_t* s, c
 FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint8_t* flags,
                                           const uint64_t* table, uint64_t* o, size_t n) {
     if (!c || !s || !p || !flags || !table || !o || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!aligned16(s) || !aligned16(p) || !aligned16(o)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     int rc = stage_table(c, table);
@@ -691,6 +697,7 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
 }
 FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !scalars || !comb || !out || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!aligned16(scalars) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     if (!c->comb_staged || memcmp(c->comb_shadow, comb, sizeof c->comb_shadow) != 0) {      // as stage_table
@@ -728,7 +735,7 @@ FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uin
 }
 
 FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {
-    if (!c || !affine || !out32 || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!c || !affine || !out32 || n > 0xffffffffu || !aligned16(affine) || !aligned16(out32)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, affine, (u64*)out32, (u32)n);
@@ -736,7 +743,7 @@ FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t*
     return FOURQ_OK;
 }
 FQ_API int fourq_decode_batch_dev(fourq_ctx* c, const uint8_t* in32, uint64_t* affine, uint8_t* status, size_t n) {
-    if (!c || !in32 || !affine || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!c || !in32 || !affine || !status || n > 0xffffffffu || !aligned16(in32) || !aligned16(affine)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)in32, affine, status, (u32)n);

@@ -30,6 +30,9 @@
  * Pointer flavours: functions ending in _dev take DEVICE pointers, enqueue on the context's
  * stream and return without synchronising (use fourq_ctx_sync or the caller's stream).  The same
  * names without _dev take HOST pointers and are synchronous (H2D copy, kernel, D2H copy).
+ * Device arrays are read and written as 16-byte vectors: every array pointer handed to a _dev function must be
+ * 16-byte aligned (FOURQ_ERR_INVALID otherwise; hipMalloc / fourq_dev_alloc / torch allocations are).  Host
+ * pointers need no particular alignment.
  */
 #ifndef FOURQ_AMD_H
 #define FOURQ_AMD_H

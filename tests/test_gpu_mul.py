@@ -164,6 +164,16 @@ def test_device_pointer_api_matches_host_api(eng):
     finally:
         eng.set_stream(None)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), eng.mul_endo(s, pts))
+    # device arrays must be 16-byte aligned (they are accessed as 16-byte vectors): a view 8 bytes in is refused
+    from fourq_amd import FourQError
+    flat = torch.empty(n * 20 + 2, dtype=torch.int64, device="cuda")
+    with pytest.raises(FourQError):
+        eng.mul_endo_dev(ds, dp, flat[1:], n)
+    with pytest.raises(FourQError):
+        eng.mul_endo_dev(ds.flatten()[1:], dp, out, n - 1)
+    eng.mul_endo_dev(ds, dp, flat[2:], n)                      # 16 bytes in is fine
+    torch.cuda.synchronize()
+    assert np.array_equal(flat[2:].reshape(n, 20).cpu().numpy().view(np.uint64), out.cpu().numpy().view(np.uint64))
 
 
 def test_full_size_cfg5_mixed_vs_c_oracle(eng):
