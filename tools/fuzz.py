@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the batched entry points against the C oracle: random batch sizes around every route
+boundary, random routing knobs, rejected points sprinkled in.  Test infrastructure (uses oracle/); GPU box.
+    python tools/fuzz.py [seconds]"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import curve4q_oracle as o
+import oracle_c as oc
+from fourq_amd import Engine, codec
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = random.Random(int(os.environ.get("FUZZ_SEED", "12345")))
+G1 = o.AffineToR1(o.Gx, o.Gy)
+g1 = codec.pack_point(G1)
+gaff = codec.pack_point((o.Gx, o.Gy))
+p392 = None
+
+
+def scalars(n):
+    return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+
+
+def pick_n(lanes):
+    edges = [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, lanes - 1, lanes, lanes + 1, 2 * lanes - 1, 2 * lanes, 2 * lanes + 1, 4 * lanes + 3]
+    return rng.choice(edges) if rng.random() < 0.5 else rng.randrange(1, 3 * lanes)
+
+
+t_end = time.time() + budget
+rounds = 0
+while time.time() < t_end:
+    knobs = {}
+    if rng.random() < 0.7:
+        knobs["FOURQ_SPLIT_MIN"] = str(rng.choice([1, 256, 1000, 70000]))
+        knobs["FOURQ_SPLIT_CHUNK"] = str(rng.choice([256, 4096, 65536, 262144]))
+        knobs["FOURQ_NORM_K"] = str(rng.choice([0, 2, 4, 8]))
+        if rng.random() < 0.3:
+            knobs["FOURQ_SPLIT_ALL"] = "1"
+    for k in ("FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL"):
+        os.environ.pop(k, None)
+    os.environ.update(knobs)
+    with Engine(0) as eng:
+        te, tw = eng.table_endo(g1), eng.table_windowed(g1)
+        if p392 is None:                                   # a point of small order (neutral after cofactor clearing)
+            import json
+            kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+
+            def unhex(v):
+                return tuple(unhex(x) for x in v) if isinstance(v, (list, tuple)) else int(v, 16)
+            p392 = codec.pack_point(unhex(kat["P392"]))
+        for _ in range(6):
+            n = pick_n(eng.lanes)
+            s = scalars(n)
+            if rng.random() < 0.2:
+                s[rng.randrange(n)] = 0
+            pts = eng.mul_endo_fixed(scalars(n), te)
+            what = rng.choice(["endo", "win", "endo_fixed", "win_fixed", "mixed", "dh_endo", "dh_win", "dh_fixed", "comb"])
+            if what == "endo":
+                ok = np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
+            elif what == "win":
+                ok = np.array_equal(eng.mul_windowed(s, pts), oc.mul(oc.WINDOWED, s, pts))
+            elif what == "endo_fixed":
+                ok = np.array_equal(eng.mul_endo_fixed(s, te), oc.mul(oc.ENDO, s, None, te))
+            elif what == "win_fixed":
+                ok = np.array_equal(eng.mul_windowed_fixed(s, tw), oc.mul(oc.WINDOWED, s, None, tw))
+            elif what == "mixed":
+                flags = np.frombuffer(rng.getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & rng.choice([1, 1, 0, 255])
+                want = np.where(flags.reshape(-1, 1) != 0, oc.mul(oc.ENDO, s, pts), oc.mul(oc.ENDO, s, None, te))
+                ok = np.array_equal(eng.mul_endo_mixed(s, pts, flags.copy(), te), want)
+            else:
+                aff = eng.prim("PT_R1TOAFFINE", pts)
+                for _bad in range(rng.randrange(0, 4)):
+                    j = rng.randrange(n)
+                    if rng.random() < 0.5:
+                        aff[j, 0] ^= np.uint64(1)          # off the curve
+                    else:
+                        aff[j] = p392                      # small order -> neutral
+                if what == "dh_endo":
+                    got, want = eng.dh_endo(s, aff), oc.dh(oc.ENDO, s, aff)
+                elif what == "dh_win":
+                    got, want = eng.dh_windowed(s, aff), oc.dh(oc.WINDOWED, s, aff)
+                elif what == "dh_fixed":
+                    t392 = eng.table_endo(codec.pack_point(o.MUL_endo(392, G1)))
+                    gg = np.repeat(gaff.reshape(1, 8), n, axis=0)
+                    got, want = eng.dh_endo(s, gg, t392), oc.dh(oc.ENDO, s, gg)
+                else:
+                    comb = eng.comb_table(codec.pack_point(o.MUL_endo(392, G1)))
+                    gg = np.repeat(gaff.reshape(1, 8), n, axis=0)
+                    got, want = eng.comb_mul(s, comb), oc.dh(oc.ENDO, s, gg)
+                ok = np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+            rounds += 1
+            print("%-10s n=%-7d knobs=%s %s" % (what, n, knobs, "ok" if ok else "MISMATCH"), flush=True)
+            if not ok:
+                sys.exit(1)
+            if time.time() > t_end:
+                break
+print("FUZZ OK: %d rounds" % rounds)
