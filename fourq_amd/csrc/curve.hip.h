@@ -86,21 +86,35 @@ FQ_DEV Proj<1, 1, 1> r2_to_r4(const R2s& t) {                          // curve4
 }
 
 // R1/R4 -> R1                                                          curve4q.py:138-152
-template <bool CH = (FQ_CHAIN != 0)> FQ_DEV R1 dbl(const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
+// CH: 0 plain, 1 chained carries, 2 chained carries on signed limbs (fp127.hip.h; the ladders only)
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0> FQ_DEV R1 dbl(const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
     Fe2<1> A = fe2_sqrx<CH>(X);
     Fe2<1> B = fe2_sqrx<CH>(Y);
     Fe2<2> C = fe2_dbl(fe2_sqrx<CH>(Z));
     Fe2<2> D = fe2_add(A, B);
-    Fe2<4> E = fe2_sub(fe2_sqrx<CH>(fe2_add(X, Y)), D);
-    Fe2<3> F = fe2_sub(B, A);
-    Fe2<6> G = fe2_sub(C, F);
-    R1 r;                      // operand roles chosen so that 8*G (second operand) and -F.im (first) are shared
-    r.X = fe2_mulx<CH>(E, G);
-    r.Z = fe2_mulx<CH>(F, G);
-    r.Y = fe2_mulx<CH>(F, D);
-    r.Ta = E;
-    r.Tb = D;
-    return r;
+    if constexpr (CH == 2) {       // signed: differences carry no bias; G (bound 4) must be a FIRST operand (8*b fits 32 bits signed)
+        Fe2<3> E = fe2_sub_signed(fe2_sqrx<CH>(fe2_add(X, Y)), D);
+        Fe2<2> F = fe2_sub_signed(B, A);
+        Fe2<4> G = fe2_sub_signed(C, F);
+        R1 r;
+        r.X = fe2_mulx<CH>(G, E);
+        r.Z = fe2_mulx<CH>(G, F);
+        r.Y = fe2_mulx<CH>(D, F);
+        r.Ta = widen<4>(E);
+        r.Tb = D;
+        return r;
+    } else {
+        Fe2<4> E = fe2_sub(fe2_sqrx<CH>(fe2_add(X, Y)), D);
+        Fe2<3> F = fe2_sub(B, A);
+        Fe2<6> G = fe2_sub(C, F);
+        R1 r;                  // operand roles chosen so that 8*G (second operand) and -F.im (first) are shared
+        r.X = fe2_mulx<CH>(E, G);
+        r.Z = fe2_mulx<CH>(F, G);
+        r.Y = fe2_mulx<CH>(F, D);
+        r.Ta = E;
+        r.Tb = D;
+        return r;
+    }
 }
 FQ_DEV R1 dbl(const R1& p) { return dbl(p.X, p.Y, p.Z); }
 
@@ -330,21 +344,27 @@ template <typename P> FQ_DEV void store_r2_limbs(P* dst, const R2& t) {
     store_fe2_limbs(dst + 2 * COORD_U32, t.E); store_fe2_limbs(dst + 3 * COORD_U32, t.F);
 }
 
+template <int CH, int A, int B> FQ_DEV auto fe2_subx(const Fe2<A>& a, const Fe2<B>& b) {
+    if constexpr (CH == 2) return widen<A + B + 1>(fe2_sub_signed(a, b)); else return fe2_sub(a, b);
+}
+template <int CH, int B> FQ_DEV auto fe2_cnegx(const Fe2<B>& x, u32 mask) {
+    if constexpr (CH == 2) return widen<B + 1>(fe2_cneg_signed(x, mask)); else return fe2_cneg(x, mask);
+}
 // Q + (+-T) for a table entry T read coordinate by coordinate from `entry` (HBM scratch or LDS):
 // ADD(Q, selectpt(s, T, R2neg(T))) of curve4q.py:232-233, :440 with R2neg(T) = (D, N, E, -F).  The N/D swap
 // of the negated entry is an address choice, -F is a two-op conditional negation, and each coordinate
 // is loaded just before the product that consumes it, which keeps the live set near 100 VGPRs.
-template <bool CH = (FQ_CHAIN != 0), typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_mask) {
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_mask) {
     const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);                          // R1toR3: curve4q.py:119-126
     Fe2<2> N1 = fe2_add(q.X, q.Y);
-    Fe2<3> D1 = fe2_sub(q.Y, q.X);
+    Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
     Fe2<1> A = fe2_mulx<CH>(D1, load_fe2_limbs(entry + off_d));    // ADD_core: curve4q.py:155-171
     Fe2<1> B = fe2_mulx<CH>(N1, load_fe2_limbs(entry + off_n));
-    Fe2<1> C = fe2_mulx<CH>(fe2_cneg(load_fe2_limbs(entry + 3 * COORD_U32), neg_mask), T);
+    Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(load_fe2_limbs(entry + 3 * COORD_U32), neg_mask), T);
     Fe2<1> D = fe2_mulx<CH>(load_fe2_limbs(entry + 2 * COORD_U32), q.Z);
-    Fe2<3> E = fe2_sub(B, A);
-    Fe2<3> F = fe2_sub(D, C);
+    Fe2<3> E = fe2_subx<CH>(B, A);
+    Fe2<3> F = fe2_subx<CH>(D, C);
     Fe2<2> G = fe2_add(D, C);
     Fe2<2> H = fe2_add(B, A);
     R1 r;                      // 8*F shared by X and Z, -G.im shared by Z and Y
@@ -367,16 +387,16 @@ template <typename P> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask) 
     t.E = load_fe2_limbs(entry + 2 * COORD_U32); t.F = load_fe2_limbs(entry + 3 * COORD_U32);
     return t;
 }
-template <bool CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_mask) {
+template <int CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_mask) {
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
-    Fe2<3> D1 = fe2_sub(q.Y, q.X);
+    Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
     Fe2<1> A = fe2_mulx<CH>(D1, t.D);
     Fe2<1> B = fe2_mulx<CH>(N1, t.N);
-    Fe2<1> C = fe2_mulx<CH>(fe2_cneg(t.F, neg_mask), T);
+    Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(t.F, neg_mask), T);
     Fe2<1> D = fe2_mulx<CH>(t.E, q.Z);
-    Fe2<3> E = fe2_sub(B, A);
-    Fe2<3> F = fe2_sub(D, C);
+    Fe2<3> E = fe2_subx<CH>(B, A);
+    Fe2<3> F = fe2_subx<CH>(D, C);
     Fe2<2> G = fe2_add(D, C);
     Fe2<2> H = fe2_add(B, A);
     R1 r;

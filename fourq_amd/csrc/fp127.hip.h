@@ -25,6 +25,8 @@ namespace fq {
 
 typedef uint32_t u32;
 typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
 
 #define FQ_DEV __device__ __forceinline__
 
@@ -241,11 +243,16 @@ template <int A, int B> FQ_DEV Fe2<1> fe2_mul_plain(const Fe2<A>& a, const Fe2<B
     r.im = fe_mac2<true>(a.re.l, b.im.l, b1x8, a.im.l, b.re.l, b0x8);
     return r;
 }
-// CH selects the variant per call site; the plain name follows the translation unit's default
-template <bool CH, int A, int B> FQ_DEV Fe2<1> fe2_mulx(const Fe2<A>& a, const Fe2<B>& b) {
-    if constexpr (CH) return fe2_mul_chain(a, b); else return fe2_mul_plain(a, b);
+// MODE selects the variant per call site (0 plain, 1 chained carries, 2 chained carries on SIGNED limbs, see the
+// signed flavour at the end of this file); the plain name follows the translation unit's default
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul_signed(const Fe2<A>& a, const Fe2<B>& b);
+template <int A> FQ_DEV Fe2<1> fe2_sqr_signed(const Fe2<A>& a);
+template <int MODE, int A, int B> FQ_DEV Fe2<1> fe2_mulx(const Fe2<A>& a, const Fe2<B>& b) {
+    if constexpr (MODE == 2) return fe2_mul_signed(a, b);
+    else if constexpr (MODE == 1) return fe2_mul_chain(a, b);
+    else return fe2_mul_plain(a, b);
 }
-template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) { return fe2_mulx<FQ_CHAIN != 0>(a, b); }
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) { return fe2_mulx<(FQ_CHAIN != 0) ? 1 : 0>(a, b); }
 // (a0 + a1 i)^2 = (a0 + a1)(a0 - a1) + (2 a0 a1) i                               fields.py:176-181
 template <int A> FQ_DEV Fe2<1> fe2_sqr_chain(const Fe2<A>& a) {
     Fe<2 * A> s = fe_add(a.re, a.im);
@@ -288,10 +295,12 @@ template <int A> FQ_DEV Fe2<1> fe2_sqr_plain(const Fe2<A>& a) {
     return r;
 }
 
-template <bool CH, int A> FQ_DEV Fe2<1> fe2_sqrx(const Fe2<A>& a) {
-    if constexpr (CH) return fe2_sqr_chain(a); else return fe2_sqr_plain(a);
+template <int MODE, int A> FQ_DEV Fe2<1> fe2_sqrx(const Fe2<A>& a) {
+    if constexpr (MODE == 2) return fe2_sqr_signed(a);
+    else if constexpr (MODE == 1) return fe2_sqr_chain(a);
+    else return fe2_sqr_plain(a);
 }
-template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) { return fe2_sqrx<FQ_CHAIN != 0>(a); }
+template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) { return fe2_sqrx<(FQ_CHAIN != 0) ? 1 : 0>(a); }
 
 // ---- canonical form, packing --------------------------------------------------------------------
 // 128-bit little-endian container (what the C ABI carries) <-> limbs.
@@ -404,6 +413,138 @@ template <int B> FQ_DEV Fe2<1> fe2_inv(const Fe2<B>& a) {
     r.re = fe_mul(n, a.re);
     r.im = fe_mul(n, fe_neg(a.im));
     return r;
+}
+
+
+// ---- signed flavour (ladder phase only) ---------------------------------------------------------------------
+// Inside the ladders the limbs are read as SIGNED 32-bit values with |limb| <= B * UNIT: a subtraction is one
+// v_sub_u32 per limb (no bias), products are v_mad_i64_i32 with arithmetic carry shifts -- 5 % fewer instructions
+// per ladder step.  Values enter the ladder with non-negative limbs (table entries, the start point) and leave it
+// through fe_unsign(), so the two flavours never mix in one operation.  hipcc must not learn that a masked limb is
+// non-negative: it would turn that operand's sign extension into a zero extension and then has no single
+// instruction for the mixed product (it emits two multiply-adds and fix-ups); FQ_SIGN_UNKNOWN hides it.
+#define FQ_SIGN_UNKNOWN(x) asm("" : "+v"(x))
+FQ_DEV i64 smul(u32 x, u32 y) { return (i64)(i32)x * (i64)(i32)y; }        // with the accumulation: one v_mad_i64_i32
+constexpr bool cols_ok_signed(u64 weighted) {
+    return weighted * 5 * 8 <= (((1ull << 63) - (1ull << 41)) / (UNIT * UNIT));
+}
+template <int B> constexpr bool fits8_signed() { return (u64)8 * B * UNIT < (1ull << 31); }
+template <int A, int B> FQ_DEV Fe<A + B> fe_sub_signed(const Fe<A>& a, const Fe<B>& b) {
+    static_assert((u64)(A + B) * UNIT < (1ull << 31), "limb overflow");
+    Fe<A + B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+template <int B> FQ_DEV Fe<B> fe_neg_signed(const Fe<B>& b) {
+    Fe<B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = 0u - b.l[i];
+    return r;
+}
+template <int B> FQ_DEV Fe<B> fe_cneg_signed(const Fe<B>& x, u32 mask) {   // -x == ~x + 1
+    Fe<B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = (x.l[i] ^ mask) - mask;
+    return r;
+}
+template <int A, int B> FQ_DEV Fe2<A + B> fe2_sub_signed(const Fe2<A>& a, const Fe2<B>& b) {
+    Fe2<A + B> r; r.re = fe_sub_signed(a.re, b.re); r.im = fe_sub_signed(a.im, b.im); return r;
+}
+template <int B> FQ_DEV Fe2<B> fe2_cneg_signed(const Fe2<B>& x, u32 mask) {
+    Fe2<B> r; r.re = fe_cneg_signed(x.re, mask); r.im = fe_cneg_signed(x.im, mask); return r;
+}
+// five limbs (in [0, 2^26) each) + the signed carry out of column 4 -> bound-1 element (2^130 == 8)
+FQ_DEV Fe<1> fe_finish_signed(u32 l0, u32 l1, u32 l2, u32 l3, u32 l4, i64 top) {
+    Fe<1> r;
+    i64 w = top * 8 + (i64)l0;               // |top| < 2^37 -> |w| < 2^41
+    r.l[0] = (u32)w & LIMB_MASK;
+    r.l[1] = l1 + (u32)(w >> LIMB_BITS);     // magnitude <= UNIT - 1
+    r.l[2] = l2; r.l[3] = l3; r.l[4] = l4;
+    FQ_SIGN_UNKNOWN(r.l[0]); FQ_SIGN_UNKNOWN(r.l[2]); FQ_SIGN_UNKNOWN(r.l[3]); FQ_SIGN_UNKNOWN(r.l[4]);
+    return r;
+}
+// The wrap-around factor 8 as (aw, bw) with aw_i * bw_j == 8 * a_i * b_j: normally (a, 8b); when 8b would not fit a
+// signed 32-bit operand, (4a, 2b) -- needed only by the squaring of a bound-2 element (DBL's (X+Y)^2).
+template <int A, int B> FQ_DEV void wrap_operands_signed(u32 aw[5], u32 bw[5], const Fe<A>& a, const Fe<B>& b) {
+    if constexpr (fits8_signed<B>()) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { aw[i] = a.l[i]; bw[i] = b.l[i] << 3; }
+    } else {
+        static_assert((u64)4 * A * UNIT < (1ull << 31) && (u64)2 * B * UNIT < (1ull << 31), "no split of the factor 8 fits");
+#pragma unroll
+        for (int i = 0; i < 5; i++) { aw[i] = a.l[i] << 2; bw[i] = b.l[i] << 1; }
+    }
+}
+#define FQ_OPAQUE(x) asm("" : "+v"(x))
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul_signed(const Fe2<A>& a, const Fe2<B>& b) {
+    static_assert(cols_ok_signed((u64)2 * A * B), "column overflow");
+    static_assert(fits8_signed<B>(), "8*b does not fit a signed 32-bit operand: swap the operands");
+    u32 b0x8[5], b1x8[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { b0x8[i] = b.re.l[i] << 3; b1x8[i] = b.im.l[i] << 3; }
+    Fe<A> na1 = fe_neg_signed(a.im);
+    i64 re = 0, im = 0;
+    u32 lr[5], li[5];
+#define FQ_COL2(K)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 5; i++) {                                         \
+        const int j = K - i;                                                                \
+        const u32 q0 = j >= 0 ? b.re.l[j >= 0 ? j : 0] : b0x8[j >= 0 ? 0 : j + 5];           \
+        const u32 q1 = j >= 0 ? b.im.l[j >= 0 ? j : 0] : b1x8[j >= 0 ? 0 : j + 5];           \
+        re += smul(a.re.l[i], q0); FQ_OPAQUE(re);                                           \
+        im += smul(a.re.l[i], q1); FQ_OPAQUE(im);                                           \
+        re += smul(na1.l[i], q1); FQ_OPAQUE(re);                                            \
+        im += smul(a.im.l[i], q0); FQ_OPAQUE(im);                                           \
+    }                                                                                       \
+    lr[K] = (u32)re & LIMB_MASK; re >>= LIMB_BITS;                                          \
+    li[K] = (u32)im & LIMB_MASK; im >>= LIMB_BITS;
+    FQ_COL2(0) FQ_COL2(1) FQ_COL2(2) FQ_COL2(3) FQ_COL2(4)
+#undef FQ_COL2
+    Fe2<1> r;
+    r.re = fe_finish_signed(lr[0], lr[1], lr[2], lr[3], lr[4], re);
+    r.im = fe_finish_signed(li[0], li[1], li[2], li[3], li[4], im);
+    return r;
+}
+template <int A> FQ_DEV Fe2<1> fe2_sqr_signed(const Fe2<A>& a) {
+    Fe<2 * A> s = fe_add(a.re, a.im);
+    Fe<2 * A> d = fe_sub_signed(a.re, a.im);
+    Fe<2 * A> t = fe_dbl(a.re);
+    static_assert((u64)2 * A * UNIT < (1ull << 31), "limb overflow");
+    static_assert(cols_ok_signed((u64)(2 * A) * (2 * A)), "column overflow");
+    u32 dw[5], s8[5], tw[5], i8[5];
+    wrap_operands_signed(dw, s8, d, s);
+    wrap_operands_signed(tw, i8, t, a.im);
+    i64 re = 0, im = 0;
+    u32 lr[5], li[5];
+#define FQ_COL2(K)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 5; i++) {                                         \
+        const int j = K - i;                                                                \
+        const u32 q0 = j >= 0 ? s.l[j >= 0 ? j : 0] : s8[j >= 0 ? 0 : j + 5];               \
+        const u32 q1 = j >= 0 ? a.im.l[j >= 0 ? j : 0] : i8[j >= 0 ? 0 : j + 5];            \
+        re += smul(j >= 0 ? d.l[i] : dw[i], q0); FQ_OPAQUE(re);                             \
+        im += smul(j >= 0 ? t.l[i] : tw[i], q1); FQ_OPAQUE(im);                             \
+    }                                                                                       \
+    lr[K] = (u32)re & LIMB_MASK; re >>= LIMB_BITS;                                          \
+    li[K] = (u32)im & LIMB_MASK; im >>= LIMB_BITS;
+    FQ_COL2(0) FQ_COL2(1) FQ_COL2(2) FQ_COL2(3) FQ_COL2(4)
+#undef FQ_COL2
+    Fe2<1> r;
+    r.re = fe_finish_signed(lr[0], lr[1], lr[2], lr[3], lr[4], re);
+    r.im = fe_finish_signed(li[0], li[1], li[2], li[3], li[4], im);
+    return r;
+}
+#undef FQ_OPAQUE
+// signed limbs of bound B -> non-negative bound-1 limbs of the same residue (leaves the signed flavour)
+template <int B> FQ_DEV Fe<1> fe_unsign(const Fe<B>& a) {
+    static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");
+    static_assert((u64)(2 * B + 1) * UNIT + (1ull << 20) < (1ull << 32), "limb overflow");
+    Fe<2 * B + 1> u;
+#pragma unroll
+    for (int i = 0; i < 5; i++) u.l[i] = a.l[i] + bias_limb(B + 1, i);
+    return fe_carry(u);
+}
+template <int B> FQ_DEV Fe2<1> fe2_unsign(const Fe2<B>& a) {
+    Fe2<1> r; r.re = fe_unsign(a.re); r.im = fe_unsign(a.im); return r;
 }
 
 }  // namespace fq

@@ -147,13 +147,34 @@ FQ_DEV void build_table_endo(const R1& P, u32* slot) {
 // The fused MUL_endo kernel runs one wave per SIMD: its ladder uses the chained products only together with
 // register-preloaded table entries (gathers issued a whole doubling ahead); measured 0.416 ms per 2^16 batch
 // against 0.423 plain and 0.463 chained without the preload (hipcc cannot hoist loads across the opaque sums).
+// Which ladders run on signed limbs (fp127.hip.h, "signed flavour"; 5 % fewer instructions per step).  Measured
+// per kernel against the unsigned chained ladder (same-box A/B): the LDS ladders gain 1-5 % and the
+// mixed-batch PREBUILT ladder 2 %; the fused kernels lose 3 %, the split windowed ladder 2 %, the split DH ladder is
+// neutral.  Hence: LDS ladders and the non-DH ENDO PREBUILT ladder only.
+#ifndef FQ_SIGNED_LADDER
+#define FQ_SIGNED_LADDER 1
+#endif
+template <int ALGO, int SRC, bool DH> constexpr bool signed_ladder() {
+    return FQ_SIGNED_LADDER && (SRC == LDS || (SRC == PREBUILT && ALGO == ENDO && !DH));
+}
 #ifndef FQ_FUSED_PRELOAD
 #define FQ_FUSED_PRELOAD 1
 #endif
 #ifndef FQ_FUSED_LADDER_CHAIN
 #define FQ_FUSED_LADDER_CHAIN 1
 #endif
-template <bool CH = (FQ_CHAIN != 0), bool PRELOAD = false, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
+// a ladder on signed limbs (CH == 2) hands its result back with non-negative limbs
+template <int CH> FQ_DEV R1 ladder_result(const R1& Q) {
+    if constexpr (CH == 2) {
+        R1 r;
+        r.X = fe2_unsign(Q.X); r.Y = fe2_unsign(Q.Y); r.Z = fe2_unsign(Q.Z);
+        r.Ta = widen<4>(fe2_unsign(Q.Ta)); r.Tb = widen<2>(fe2_unsign(Q.Tb));
+        return r;
+    } else {
+        return Q;
+    }
+}
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
     Proj<1, 1, 1> q4 = start_table(tbl + (e.top & 7) * stride, 0u);        // s[64] = 1: the entry itself
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
@@ -169,9 +190,9 @@ template <bool CH = (FQ_CHAIN != 0), bool PRELOAD = false, typename TP> FQ_DEV R
             Q = add_table<CH>(Q, entry, endo_neg_mask(e, i));
         }
     }
-    return Q;
+    return ladder_result<CH>(Q);
 }
-template <bool CH = (FQ_CHAIN != 0), bool PRELOAD = false, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
     Proj<1, 1, 1> q4 = start_table(tbl + (code & 7) * stride, (code >> 3) - 1u);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
@@ -191,7 +212,7 @@ template <bool CH = (FQ_CHAIN != 0), bool PRELOAD = false, typename TP> FQ_DEV R
             Q = add_table<CH>(Q, entry, neg);
         }
     }
-    return Q;
+    return ladder_result<CH>(Q);
 }
 
 // The same table for the fused kernels (one wave per SIMD, up to 512 registers per lane).  gfx950 counts loads and
@@ -331,11 +352,11 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             u64 v[4];
             decompose(m, v);
             EndoDigits e = recode(v);
-            constexpr bool CH = (FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN);
+            constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
             Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(e, tbl, R2_LIMBS);
         } else {
             WinScalar w = win_reduce(m);
-            constexpr bool CH = (FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN);
+            constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
             Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(w, tbl, R2_LIMBS);
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
