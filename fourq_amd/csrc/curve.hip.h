@@ -410,23 +410,29 @@ template <int CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_m
 // Q + (+-A) for a precomputed AFFINE point A = (x+y, y-x, 2d*x*y) read from `entry` (three coordinates of
 // COORD_U32 dwords): ADD_core with the table point's 2Z = 2, i.e. D = 2*Z1 costs no multiplication.  Used by
 // the fixed-base comb, not by the reference-shaped MUL_* paths.
-template <typename P> FQ_DEV R1 add_affine_table(const R1& q, const P* entry, u32 neg_mask) {
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_affine_table(const R1& q, const P* entry, u32 neg_mask) {
     const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
-    Fe2<1> T = fe2_mul(q.Ta, q.Tb);
+    Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
-    Fe2<3> D1 = fe2_sub(q.Y, q.X);
-    Fe2<1> A = fe2_mul(D1, load_fe2_limbs(entry + off_d));
-    Fe2<1> B = fe2_mul(N1, load_fe2_limbs(entry + off_n));
-    Fe2<1> C = fe2_mul(fe2_cneg(load_fe2_limbs(entry + 2 * COORD_U32), neg_mask), T);
+    Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
+    Fe2<1> A = fe2_mulx<CH>(D1, load_fe2_limbs(entry + off_d));
+    Fe2<1> B = fe2_mulx<CH>(N1, load_fe2_limbs(entry + off_n));
+    Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(load_fe2_limbs(entry + 2 * COORD_U32), neg_mask), T);
     Fe2<2> D = fe2_dbl(q.Z);
-    Fe2<3> E = fe2_sub(B, A);
-    Fe2<4> F = fe2_sub(D, C);
+    Fe2<3> E = fe2_subx<CH>(B, A);
     Fe2<3> G = fe2_add(D, C);
     Fe2<2> H = fe2_add(B, A);
     R1 r;
-    r.X = fe2_mul(E, F);
-    r.Z = fe2_mul(G, F);
-    r.Y = fe2_mul(G, H);
+    if constexpr (CH == 2) {       // signed: D - C has bound 3 and fits the 8*b operand
+        Fe2<3> F = fe2_sub_signed(D, C);
+        r.X = fe2_mulx<CH>(E, F);
+        r.Z = fe2_mulx<CH>(G, F);
+    } else {
+        Fe2<4> F = fe2_sub(D, C);
+        r.X = fe2_mulx<CH>(E, F);
+        r.Z = fe2_mulx<CH>(G, F);
+    }
+    r.Y = fe2_mulx<CH>(G, H);
     r.Ta = widen<4>(E);
     r.Tb = H;
     return r;

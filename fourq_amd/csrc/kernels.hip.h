@@ -397,6 +397,7 @@ constexpr int COMB_LDS_U32 = COMB_ENTRY_U32 + 4;              // padded stride i
 
 #if FQ_CHAIN   // only fourq_chain.hip launches it
 // [m]B, affine, from the comb: 9 doublings + 49 mixed additions per element
+constexpr int COMB_MODE = FQ_SIGNED_LADDER ? 2 : 1;          // the comb's additions run on signed limbs like the LDS ladders
 template <bool DEFER>
 __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
     __shared__ __attribute__((aligned(16))) u32 lds[COMB_POINTS * COMB_LDS_U32];
@@ -421,10 +422,11 @@ __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, cons
                 const u32* entry = lds + ((j << (COMB_W - 1)) + comb_index(c, col)) * COMB_LDS_U32;
                 const u32 neg = comb_neg_mask(c, col);
                 if (i == COMB_E - 1 && j == 0) { Q = affine_table_start(entry, neg); continue; }
-                if (j == 0) Q = dbl(Q.X, Q.Y, Q.Z);
-                Q = add_affine_table(Q, entry, neg);
+                if (j == 0) Q = dbl<COMB_MODE>(Q.X, Q.Y, Q.Z);
+                Q = add_affine_table<COMB_MODE>(Q, entry, neg);
             }
         }
+        Q = ladder_result<COMB_MODE>(Q);
         if (DEFER) {                                          // deferred normalisation, see normalize_kernel
             if (live) {
                 store_proj(proj, proj_stride, id, fe2_carry(fe2_cneg(Q.X, c.negate)), Q.Y, Q.Z);   // even scalar: -(x, y) = (-x, y)
