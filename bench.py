@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- FourQ scalar-mults/sec, BASELINE.json config 2 per GPU.
+"""bench.py -- FourQ scalar-mults/sec: BASELINE.json config 2 per GPU as the headline, configs 3-5 beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
 
-One step = one pass of the hot path over one batch: 2^16 variable-base MUL_endo(m_i, P_i) per GPU
-(random 256-bit scalars; P_i = projective N-torsion points, raw R1 outputs of fixed-base [k_i]G),
-inputs and outputs resident in HBM.  `--workload cfg3|cfg4|cfg5` runs the other BASELINE.json
-configurations at their per-GPU sizes (the headline the driver records is the default, cfg2).  Ranks are independent (weak scaling, no data-path
-collective).  Rank 0 prints ONE JSON line.  Synthetic data; integer arithmetic (dtype "u32x5"
-limbs of GF(2^127-1), reported as "u64" words at the ABI).
+`--gpus N` with N > 1 started from a bare shell launches its own N rank processes (python -m
+torch.distributed.run on 127.0.0.1, a free port) BEFORE anything touches a GPU and relays rank 0's line; started
+under torch.distributed.run (RANK in the environment) it is one of the ranks.  FOURQ_BENCH_REHEARSE=1 puts every
+rank on GPU 0 over gloo (rehearsal of the N > 1 code on a one-GPU box; at most 6 ranks).
+
+One step = one pass of the hot path over one batch: 2^16 variable-base MUL_endo(m_i, P_i) per GPU (random 256-bit
+scalars; P_i = projective N-torsion points, raw R1 outputs of fixed-base [k_i]G), inputs and outputs resident in
+HBM.  The default run then measures configs 3, 4, 5 at their per-GPU sizes (nested under "configs") and, on one GPU,
+the PCIe-inclusive rate of the host-array API ("pcie_inclusive") and the CPU baseline.  Ranks are independent (weak
+scaling, no data-path collective); the one collective of the path, the gather of results, is timed apart
+("gather_ms").  Every rank checks every output of its shard against the C restatement of the reference before
+anything is reported.  Rank 0 prints ONE JSON line.  Synthetic data; integer arithmetic (u32 x 5 limbs of
+GF(2^127-1) inside, "u64" words at the ABI).
 """
 import argparse
 import json
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +32,44 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md
 VALU_MAD_PEAK = 1024 * 64 / 4.0 * 2.4e9    # measured: a wave64 v_mad_u64_u32 occupies a SIMD for 4 cycles (profiles/true_rates_r01.txt)
 
+# Per workload: algorithmic bytes per unit and algorithmic 32x32->64 multiply-adds per unit (both SURVEY.md 8d: GF(p)
+# mul = 16, GF(p^2) M = 48, S = 32 on the reference's real M/S counts), and the multiply-adds this implementation
+# EXECUTES per unit in radix 2^26 (M = 100, S = 50; DBL = 3M+4S = 500, ADD = 8M = 800; ladder step 1 300 x 64 endo,
+# 4 DBL + ADD = 2 800 x 62 windowed; table_endo 14 300; DH extras 8 600 (6 800 with the shared inversion); comb
+# 9 DBL + 49 mixed ADD (7M) = 38 800 + inversion): DESIGN.md section 5.
+WORKLOADS = {
+    "cfg2": dict(batch=1 << 16, steps=500, bytes=32 + 160 + 160, alg_mads=49_440, mads=97_600, seed=20002,
+                 kernel="ladder_kernel<ENDO, FUSED>", unit="MUL_endo(m, P), variable base",
+                 text="BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
+                      "projective N-torsion points, raw R1 in/out resident in HBM"),
+    "cfg3": dict(batch=1 << 20, steps=60, bytes=32 + 160, alg_mads=91_264, mads=173_600, seed=30002,
+                 kernel="ladder_kernel<WINDOWED, LDS>", unit="MUL_windowed(m, G, table)",
+                 text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
+    "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, mads=39_400 + 97_600 + 6_800, seed=40002,
+                 kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
+                 unit="exchange = DH_endo(a, DH_endo(b, G)): two DH_core evaluations",
+                 text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
+                      "(first half fixed-base through the 80-point comb of [392]G, same affine outputs as with table_endo([392]G); "
+                      "second half variable-base); affine in/out"),
+    "cfg5": dict(batch=1 << 17, steps=300, bytes=(192 + 352) // 2, alg_mads=(41_984 + 49_440) // 2, mads=(83_300 + 97_600) // 2, seed=50002,
+                 kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer",
+                 unit="MUL_endo, 50% fixed base / 50% variable base",
+                 text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo; "
+                      "the 'persistent kernel + device-side queue' of the config is realised as device-side compaction + ONE "
+                      "pointer-selected ladder launch per round (DESIGN.md section 5: measured faster, results identical)"),
+}
+RANK_SEED_STRIDE = 16        # rank r draws from seed + 16 r (rank 0 = the seeds of SURVEY.md 8d)
+
 
 def seeded_scalars(seed, n):
     import numpy as np
     rng = random.Random(seed)
     return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+
+
+def seeded_flags(seed, n):
+    import numpy as np
+    return (np.frombuffer(random.Random(seed).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
 
 
 def host_cores():
@@ -55,25 +95,39 @@ def host_cores():
     return min(cores, int(os.environ.get("FOURQ_BENCH_CORES", "16")))
 
 
+# ---- CPU baseline (the oracle is the checker and the thing timed here, never part of the GPU path) --------------
 def _cpu_worker(args):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import curve4q_oracle as o
     kind, items, extra = args
     G = (o.Gx, o.Gy)
+    G1 = o.AffineToR1(o.Gx, o.Gy)       # with a table the reference ignores the point (curve4q.py:209, :426)
     t0 = time.perf_counter()
-    if kind == "mul_endo":
+    if kind == "cfg2":
         outs = [o.MUL_endo(m, P) for m, P in items]
-    elif kind == "mul_windowed_fixed":
-        outs = [o.MUL_windowed(m, None_r1(o), table=extra) for m in items]
-    elif kind == "dh_exchange":
+    elif kind == "cfg3":
+        outs = [o.MUL_windowed(m, G1, table=extra) for m in items]
+    elif kind == "cfg4":
         outs = [o.DH_endo(a, o.DH_endo(b, G, table=extra)) for a, b in items]
-    else:  # mixed: (m, P or None)
-        outs = [o.MUL_endo(m, P) if P is not None else o.MUL_endo(m, None_r1(o), table=extra) for m, P in items]
+    else:  # cfg5: (m, P or None)
+        outs = [o.MUL_endo(m, P) if P is not None else o.MUL_endo(m, G1, table=extra) for m, P in items]
     return time.perf_counter() - t0, outs
 
 
-def None_r1(o):
-    return o.AffineToR1(o.Gx, o.Gy)     # with a table the reference ignores the point (curve4q.py:209, :426)
+def cpu_items(workload, d, sample):
+    """(items, extra, text) of the Python-oracle leg: the first `sample` units of one workload's batch."""
+    from fourq_amd import codec
+    ms = codec.unpack_scalars(d["scalars_h"][:sample])
+    if workload == "cfg2":
+        return list(zip(ms, codec.unpack_points(d["points_h"][:sample]))), None, "MUL_endo(m, P)"
+    if workload == "cfg3":
+        return ms, codec.unpack_table(d["table_h"]), "MUL_windowed(m, G, table)"
+    if workload == "cfg4":
+        import curve4q_oracle as o
+        t392 = o.table_endo(o.MUL_endo(392, o.AffineToR1(o.Gx, o.Gy)))
+        return list(zip(ms, codec.unpack_scalars(d["second_h"][:sample]))), t392, "DH_endo(a, DH_endo(b, G, table))"
+    pts = codec.unpack_points(d["points_h"][:sample])
+    return [(m, P if f else None) for m, P, f in zip(ms, pts, d["flags_h"][:sample])], codec.unpack_table(d["table_h"]), "50/50 fixed/variable MUL_endo"
 
 
 def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
@@ -102,36 +156,36 @@ def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
             "per_core": round(per_core / busy, 1)}
 
 
-def c_port_baseline(workload, scalars_h, second_h, points_h, table_h, flags_h, expected_words):
-    """The C restatement (oracle/fourq_oracle.c, OpenMP) over the WHOLE timed batch: a second parity gate on every
-    output and, for context, its rate on the same host cores."""
-    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
+def c_oracle_gate(workload, data, got_words):
+    """The C restatement (oracle/fourq_oracle.c, OpenMP) over the WHOLE batch of this rank: the parity gate on every
+    output and, for context, its rate on the host cores.  Returns (units per second, threads)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_c as oc
     from fourq_amd import codec, constants
-    oc.lib()
+    threads = oc.set_num_threads(host_cores())
+    assert threads == host_cores(), "OpenMP did not take the thread count"
+    s, k = data["scalars_h"], data["second_h"]
     t0 = time.perf_counter()
     if workload == "cfg2":
-        got = oc.mul(oc.ENDO, scalars_h, points_h)
+        want = oc.mul(oc.ENDO, s, data["points_h"])
     elif workload == "cfg3":
-        got = oc.mul(oc.WINDOWED, scalars_h, None, table_h)
+        want = oc.mul(oc.WINDOWED, s, None, data["table_h"])
     elif workload == "cfg4":
-        g = np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), len(scalars_h), axis=0)
-        mid, st1 = oc.dh(oc.ENDO, second_h, g)
-        got, st2 = oc.dh(oc.ENDO, scalars_h, mid)
+        g = np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), len(s), axis=0)
+        mid, st1 = oc.dh(oc.ENDO, k, g)
+        want, st2 = oc.dh(oc.ENDO, s, mid)
         if st1.any() or st2.any():
             raise SystemExit("cfg4: unexpected DH failure status in the C oracle")
     else:
-        fixed = oc.mul(oc.ENDO, scalars_h, None, table_h)
-        var = oc.mul(oc.ENDO, scalars_h, points_h)
-        got = np.where(flags_h.reshape(-1, 1) != 0, var, fixed)
+        fixed = oc.mul(oc.ENDO, s, None, data["table_h"])
+        var = oc.mul(oc.ENDO, s, data["points_h"])
+        want = np.where(data["flags_h"].reshape(-1, 1) != 0, var, fixed)
     dt = time.perf_counter() - t0
-    if not np.array_equal(got, expected_words):
+    if not np.array_equal(want, got_words):
         raise SystemExit("PARITY FAILURE: GPU result differs from the C oracle on the full batch (%s)" % workload)
-    units = len(scalars_h) * (2 if workload == "cfg5" else 1)     # cfg5 evaluates both variants of every element
-    return {"value": round(units / dt, 1), "unit": "scalar-mults/s", "threads": oc.num_threads(), "cores": host_cores(), "kind": "port",
-            "sample": "whole batch (%d units) via oracle/fourq_oracle.c, every output compared bit-exact with the GPU's" % len(scalars_h)}
+    units = len(s) * (2 if workload in ("cfg4", "cfg5") else 1)     # cfg5 evaluates both variants, cfg4 both halves
+    return units / dt, threads, want
 
 
 def edge_case_check(eng):
@@ -163,195 +217,332 @@ def edge_case_check(eng):
     return 3 * len(cases)
 
 
-# per-workload constants: algorithmic bytes per unit and v_mad_u64_u32 issued per unit by this
-# implementation, counted from the formulas: GF(p^2) M = 100, S = 50; DBL = 3M+4S = 500,
-# ADD = 8M = 800; ladder step 1 300 (x64 endo, 4 DBL + ADD = 2 800 x62 windowed); table_endo 14 300;
-# DH extras (membership, x392, inversion) 8 600; comb 9 DBL + 49 mixed ADD (7M) = 38 800 + inversion 2 500; at cfg4's size
-# eight elements share one inversion (normalize_kernel<8>): -1 800 per DH_core
-WORKLOADS = {
-    "cfg2": dict(batch=1 << 16, bytes=32 + 160 + 160, mads=97_600, kernel="ladder_kernel<ENDO, FUSED>",
-                 text="BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
-                      "projective N-torsion points, raw R1 in/out resident in HBM"),
-    "cfg3": dict(batch=1 << 20, bytes=32 + 160, mads=173_600, kernel="ladder_kernel<WINDOWED, LDS>",
-                 text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
-    "cfg4": dict(batch=1 << 19, bytes=2 * 161, mads=39_400 + 97_600 + 6_800, kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
-                 text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
-                      "(first half fixed-base through the 80-point comb of [392]G, same affine outputs as with table_endo([392]G); "
-                      "second half variable-base); affine in/out"),
-    "cfg5": dict(batch=1 << 17, bytes=(192 + 352) // 2, mads=(83_300 + 97_600) // 2, kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer",
-                 text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo"),
-}
+# ---- one workload on this rank ---------------------------------------------------------------------------------
+class Bench:
+    def __init__(self, rank, local_rank, world, rehearse):
+        import torch
+        from fourq_amd import Engine, codec, constants
+        self.rank, self.world, self.rehearse = rank, world, rehearse
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.stream = torch.cuda.Stream(device=self.dev)     # a real (non-null) stream: the engine launches on it, the events time it
+        torch.cuda.set_stream(self.stream)
+        self.eng = Engine(local_rank, stream=self.stream.cuda_stream)
+        G_aff = (constants.Gx, constants.Gy)
+        self.g1 = codec.pack_point(G_aff + ((1, 0),) + G_aff)
+        self.g_aff = codec.pack_point(G_aff)
+        self.table_g = self.eng.table_endo(self.g1)
+        self.settle_ms = float(os.environ.get("FOURQ_BENCH_SETTLE_MS", "80"))
+
+    def to_dev(self, a):
+        import numpy as np
+        import torch
+        a = np.ascontiguousarray(a)
+        return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(self.dev)
+
+    def prepare(self, workload, n):
+        """Synthetic inputs of SURVEY.md 8d, generated on the GPU; returns (step function, data dict)."""
+        import numpy as np
+        import torch
+        eng, wl = self.eng, WORKLOADS[workload]
+        seed = wl["seed"] + RANK_SEED_STRIDE * self.rank
+        d = {}
+        if workload == "cfg5":                       # flags: seed 50002, points: 50003, scalars: 50004
+            d["flags_h"] = seeded_flags(seed, n)
+            d["second_h"] = seeded_scalars(seed + 1, n)
+            d["scalars_h"] = seeded_scalars(seed + 2, n)
+        else:
+            d["scalars_h"] = seeded_scalars(seed, n)
+            d["second_h"] = seeded_scalars(seed + 1, n)
+        scalars, second = self.to_dev(d["scalars_h"]), self.to_dev(d["second_h"])
+        out = torch.empty((n, 20), dtype=torch.int64, device=self.dev)
+        if workload in ("cfg2", "cfg5"):
+            points = torch.empty((n, 20), dtype=torch.int64, device=self.dev)
+            eng.mul_endo_fixed_dev(second, self.table_g, points, n)          # P_i = [k_i]G, raw R1 (projective, Z != 1)
+            torch.cuda.synchronize()
+            d["points_h"] = points.cpu().numpy().view(np.uint64)
+        if workload == "cfg2":
+            def step():
+                eng.mul_endo_dev(scalars, points, out, n)
+        elif workload == "cfg3":
+            d["table_h"] = eng.table_windowed(self.g1)
+
+            def step():
+                eng.mul_windowed_fixed_dev(scalars, d["table_h"], out, n)
+        elif workload == "cfg4":
+            from fourq_amd import codec
+            g392 = eng.mul_endo(codec.pack_scalars([392]), self.g1.reshape(1, 20))[0]      # curve4q.py:758
+            comb_h = eng.comb_table(g392)                                     # 80-point comb of [392]G (draft :725-729)
+            mid = torch.empty((n, 8), dtype=torch.int64, device=self.dev)
+            out = torch.empty((n, 8), dtype=torch.int64, device=self.dev)
+            st1 = torch.empty(n, dtype=torch.uint8, device=self.dev)
+            st2 = torch.empty(n, dtype=torch.uint8, device=self.dev)
+            d["status"] = (st1, st2)
+
+            def step():
+                eng.comb_mul_dev(second, comb_h, mid, st1, n)             # == DH_endo(b, G, table_endo([392]G)), affine
+                eng.dh_endo_dev(scalars, mid, None, out, st2, n)          # DH_endo(a, .)
+        else:
+            d["table_h"] = self.table_g
+            flags = self.to_dev(d["flags_h"])
+
+            def step():
+                eng.mul_endo_mixed_dev(scalars, points, flags, d["table_h"], out, n)
+        d["out"] = out
+        d["keep"] = (scalars, second)
+        return step, d
+
+    def run(self, workload, n, steps, warmup):
+        """W warm-up steps, then K timed steps between barrier + synchronize on both sides; MAX over ranks."""
+        import torch
+        import torch.distributed as dist
+        wl = WORKLOADS[workload]
+        step, d = self.prepare(workload, n)
+        torch.cuda.synchronize()
+        # The clock governor needs ~35 ms of load to reach the sustained clock (tools/clock_ramp.py,
+        # profiles/clock_ramp_r01.txt: 0.43 ms per launch cold, 0.364 ms from launch 100 on).  Throughput is a
+        # sustained-rate metric, so the device is brought to that state before the W warm-up steps; untimed.
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < self.settle_ms:
+            for _ in range(8 if n <= 1 << 17 else 1):
+                step()
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            step()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(self.stream)                      # HIP events on the launch stream, around the K timed steps
+        for _ in range(steps):
+            step()
+        ev1.record(self.stream)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1) / max(1, steps)      # average launch duration, inter-launch gaps included
+        if self.world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.rehearse else self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if workload == "cfg4" and (bool(d["status"][0].any()) or bool(d["status"][1].any())):
+            raise SystemExit("cfg4: unexpected DH failure status")
+        total = n * self.world * steps
+        ach_gbs = wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9
+        rec = {
+            "workload": wl["text"], "unit_of_work": wl["unit"], "batch_per_gpu": n, "steps": steps, "warmup": warmup,
+            "value": round(total / elapsed, 1), "unit": "scalar-mults/s" if workload != "cfg4" else "exchanges/s",
+            "ms_per_step": round(1e3 * elapsed / steps, 4),
+            "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic(workload),
+                         "kernel": wl["kernel"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n,
+                         "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
+            "valu_roofline": {
+                "bound": "valu-int (v_mad_u64_u32, 4 cycles per wave64 per SIMD)", "peak": round(VALU_MAD_PEAK / 1e12, 3), "unit": "Tmad/s",
+                "algorithmic_mads_per_unit": wl["alg_mads"], "executed_mads_per_unit": wl["mads"],
+                "algorithmic_frac": round(wl["alg_mads"] * n / (kernel_ms * 1e-3) / VALU_MAD_PEAK, 4),
+                "executed_frac": round(wl["mads"] * n / (kernel_ms * 1e-3) / VALU_MAD_PEAK, 4),
+                "note": "algorithmic = SURVEY.md 8(d) units (GF(p) mul = 16 multiply-adds on 2x64-bit limbs); executed = what the "
+                        "radix-2^26 lazy-limb layout issues (25 per GF(p) mul, no carry chains)"},
+        }
+        return rec, d
+
+    def parity_gate(self, workload, d):
+        """Every output of this rank's shard against the C oracle; raises on any difference."""
+        import numpy as np
+        got = d["out"].cpu().numpy().view(np.uint64)
+        rate, threads, want = c_oracle_gate(workload, d, got)
+        return {"gate": "every output of the shard bit-exact vs oracle/fourq_oracle.c", "ok": True, "units": int(len(got)),
+                "c_oracle_units_per_s": round(rate, 1), "c_oracle_threads": threads}, got, want
+
+    def gather_ms(self, out, n, reps=3):
+        """The path's only collective: results gathered to rank 0 (RCCL over xGMI; gloo in rehearsals).  Median of `reps`."""
+        import torch
+        import torch.distributed as dist
+        from fourq_amd.dist import gather_rows
+        times, full = [], None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            full = gather_rows(out, n * self.world, dst=0)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        if self.rank == 0:
+            assert full.shape[0] == n * self.world
+        return round(sorted(times)[len(times) // 2], 3)
+
+    def pcie_inclusive(self, workload, d, want_words, reps):
+        """SURVEY.md 8(d) wall-clock metric: first H2D byte to last D2H byte through the host-array ABI, from
+        host-resident inputs in pinned memory (fourq_host_alloc); the pageable-caller rate beside it.  Outputs are
+        compared with the C oracle's."""
+        import numpy as np
+        eng = self.eng
+        n = len(d["scalars_h"])
+        s_pin = eng.host_array(d["scalars_h"])
+        out_pin = eng.host_empty((n, 20))
+        if workload == "cfg2":
+            p_pin = eng.host_array(d["points_h"])
+            call = lambda s, p, o: eng.mul_endo(s, p, out=o)
+            args_pin, args_page = (s_pin, p_pin, out_pin), (d["scalars_h"], d["points_h"], None)
+            bytes_in, bytes_out = 192, 160
+        else:
+            call = lambda s, p, o: eng.mul_windowed_fixed(s, p, out=o)
+            args_pin, args_page = (s_pin, d["table_h"], out_pin), (d["scalars_h"], d["table_h"], None)
+            bytes_in, bytes_out = 32, 160
+        rec = {"io": "R1 in / R1 out: %d B in + %d B out per op (the reference's own MUL_* signature)" % (bytes_in, bytes_out),
+               "batch": n, "reps": reps}
+        for label, args in (("pinned", args_pin), ("pageable", args_page)):
+            call(*args)                                         # sizes the pipeline's buffers
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                got = call(*args)
+            dt = (time.perf_counter() - t0) / reps
+            if not np.array_equal(got, want_words):
+                raise SystemExit("PARITY FAILURE: host-array path (%s, %s) differs from the C oracle" % (workload, label))
+            st = eng.host_stats()
+            r = {"value": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 4), "gbs_h2d": round(st["gbs_h2d"], 2), "gbs_d2h": round(st["gbs_d2h"], 2),
+                 "chunks": st["chunks"], "wall_gbs_both_directions": round(n * (bytes_in + bytes_out) / dt / 1e9, 2)}
+            if label == "pinned":
+                rec.update(r)
+            else:
+                rec["pageable_caller"] = r
+        rec["note"] = ("value = units / wall-clock of the synchronous host-array call (H2D, kernels, D2H pipelined over chunks of whole "
+                       "kernel generations); gbs_* = bytes / summed copy durations (HIP events on the copy streams), i.e. the link rate while a "
+                       "copy is running; every output compared with the C oracle")
+        for a in (s_pin, out_pin) + ((p_pin,) if workload == "cfg2" else ()):
+            eng.host_free(a)
+        return rec
+
+
+def _pmc_traffic(workload="cfg2"):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            data = json.load(fh)
+        if workload == "cfg2":
+            return data.get("hbm_bytes_per_launch")
+        return (data.get("per_workload") or {}).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+# ---- launcher ----------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    """`bench.py --gpus N` from a bare shell: N fresh rank processes under torch.distributed.run.  This process never
+    imports torch.cuda or creates an engine, and nothing that has touched a GPU is re-exec'd."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps of the headline workload (default 500 for cfg2; the workload's own default otherwise)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2", help="BASELINE.json configuration (default: the headline, cfg2)")
     ap.add_argument("--batch", type=int, default=0, help="units per GPU per step (default: the workload's BASELINE size)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the pure-Python CPU baseline leg (rank 0)")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip the nested cfg3/cfg4/cfg5 records")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive host-array measurement")
+    ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the whole-shard C-oracle gate")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from fourq_amd import Engine, codec, constants
-    from fourq_amd.dist import gather_rows, init_process_group
+    from fourq_amd import codec
+    from fourq_amd.dist import env_rank
 
     # FOURQ_BENCH_REHEARSE=1: every rank on GPU 0 over gloo -- exercises the N>1 code path on a one-GPU box
     rehearse = os.environ.get("FOURQ_BENCH_REHEARSE") == "1"
-    rank, local_rank, world = init_process_group("gloo" if rehearse else "nccl")
+    rank, local_rank, world = env_rank()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if rehearse:
         local_rank = 0
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.Stream(device=dev)     # a real (non-null) stream: the engine launches on it, the events time it
-    torch.cuda.set_stream(stream)
-    eng = Engine(local_rank, stream=stream.cuda_stream)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world)
+    b = Bench(rank, local_rank, world, rehearse)
 
     wl = WORKLOADS[args.workload]
     n = args.batch or wl["batch"]
-    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
-    # ---- synthetic workload, generated on the GPU: rank r uses seeds base+2r, base+1+2r
-    seed = {"cfg2": 20002, "cfg3": 30002, "cfg4": 40002, "cfg5": 50002}[args.workload] + 2 * rank
-    G_aff = (constants.Gx, constants.Gy)
-    g1 = codec.pack_point(G_aff + ((1, 0),) + G_aff)
-    table_g = eng.table_endo(g1)
-    scalars_h = seeded_scalars(seed, n)
-    scalars = to_dev(scalars_h)
-    second_h = seeded_scalars(seed + 1, n)
-    second = to_dev(second_h)
-    points = torch.empty((n, 20), dtype=torch.int64, device=dev)
-    eng.mul_endo_fixed_dev(second, table_g, points, n)          # P_i = [k_i]G, raw R1 (projective, Z != 1)
-    out = torch.empty((n, 20), dtype=torch.int64, device=dev)
-    extra_h = None
-    if args.workload == "cfg2":
-        def step():
-            eng.mul_endo_dev(scalars, points, out, n)
-    elif args.workload == "cfg3":
-        extra_h = eng.table_windowed(g1)
+    steps = args.steps or wl["steps"]
+    rec, d = b.run(args.workload, n, steps, args.warmup)
+    parity, got, want = ({"gate": "skipped (--no-parity)", "ok": None}, None, None) if args.no_parity else b.parity_gate(args.workload, d)
+    gather = b.gather_ms(d["out"], n) if world > 1 else None
 
-        def step():
-            eng.mul_windowed_fixed_dev(scalars, extra_h, out, n)
-    elif args.workload == "cfg4":
-        g392 = eng.mul_endo(codec.pack_scalars([392]), g1.reshape(1, 20))[0]      # curve4q.py:758
-        extra_h = eng.table_endo(g392)
-        g_aff = to_dev(np.repeat(codec.pack_point(G_aff).reshape(1, 8), n, axis=0))
-        mid = torch.empty((n, 8), dtype=torch.int64, device=dev)
-        out = torch.empty((n, 8), dtype=torch.int64, device=dev)
-        st1 = torch.empty(n, dtype=torch.uint8, device=dev)
-        st2 = torch.empty(n, dtype=torch.uint8, device=dev)
+    configs = {}
+    others = [] if (args.no_configs or args.batch) else [w for w in sorted(WORKLOADS) if w != args.workload]
+    for w in others:
+        r, dw = b.run(w, WORKLOADS[w]["batch"], WORKLOADS[w]["steps"], max(2, args.warmup // 4))
+        if args.no_parity:
+            r["parity"], want_w = {"gate": "skipped (--no-parity)", "ok": None}, None
+        else:
+            r["parity"], _, want_w = b.parity_gate(w, dw)
+        if world > 1 and w == "cfg4":
+            r["gather_ms"] = b.gather_ms(dw["out"], WORKLOADS[w]["batch"])
+        if world == 1 and w == "cfg3" and not args.no_pcie and want_w is not None:
+            r["pcie_inclusive"] = b.pcie_inclusive("cfg3", dw, want_w, reps=3)
+        configs[w] = r
+        del dw
+        torch.cuda.empty_cache()
 
-        comb_h = eng.comb_table(g392)                                     # 80-point comb of [392]G (draft :725-729)
-
-        def step():
-            eng.comb_mul_dev(second, comb_h, mid, st1, n)             # == DH_endo(b, G, table_endo([392]G)), affine
-            eng.dh_endo_dev(scalars, mid, None, out, st2, n)          # DH_endo(a, .)
-    else:
-        extra_h = table_g
-        flags_h = (np.frombuffer(random.Random(seed + 7).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
-        flags = torch.from_numpy(flags_h).to(dev)
-
-        def step():
-            eng.mul_endo_mixed_dev(scalars, points, flags, extra_h, out, n)
-    torch.cuda.synchronize()
-
-    # The clock governor needs ~35 ms of load to reach the sustained clock (tools/clock_ramp.py,
-    # profiles/clock_ramp_r01.txt: 0.43 ms per launch cold, 0.364 ms from launch 100 on).  Throughput is a
-    # sustained-rate metric, so the device is brought to that state before the W warm-up steps; untimed.
-    settle_ms = float(os.environ.get("FOURQ_BENCH_SETTLE_MS", "80"))
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < settle_ms:
-        for _ in range(8):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)                      # HIP events on the launch stream, around the K timed steps
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)      # average launch duration, inter-launch gaps included
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    # ---- plumbing check of the only collective the path has: gather the results once (untimed)
-    gathered = gather_rows(out, n * world, dst=0) if world > 1 else out
+    if world > 1:                                           # every rank passed its own gate, or the job has already died
+        ok = torch.tensor([1.0 if parity["ok"] in (True, None) else 0.0], device="cpu" if rehearse else b.dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        parity["all_ranks_ok"] = bool(ok.item() == 1.0)
     if rank == 0:
-        assert gathered.shape[0] == n * world
-        total = n * world * args.steps
-        value = total / elapsed
-        ach_gbs = wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9
-        mad_rate = wl["mads"] * n / (kernel_ms * 1e-3)
         line = {
-            "metric": "FourQ scalar-mults/sec (batch, whole node)", "value": round(value, 1), "unit": "scalar-mults/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "metric": "FourQ scalar-mults/sec (batch, whole node)", "value": rec["value"], "unit": rec["unit"],
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": wl["text"], "batch_per_gpu": n, "parallelism": "independent shards x%d, no data-path collective" % world,
-                       "clock_settle_ms": settle_ms},
-            "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic() if args.workload == "cfg2" else None,
-                         "kernel": wl["kernel"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n,
-                         "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
-            "valu_roofline": {"bound": "valu-int (v_mad_u64_u32, 4 cycles per wave64 per SIMD)", "achieved": round(mad_rate / 1e12, 3),
-                              "peak": round(VALU_MAD_PEAK / 1e12, 3), "unit": "Tmad/s", "frac": round(mad_rate / VALU_MAD_PEAK, 4)},
+            "config": {"workload": rec["workload"], "batch_per_gpu": n, "parallelism": "independent shards x%d, no data-path collective" % world,
+                       "clock_settle_ms": b.settle_ms, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                       "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if world > 1 else None},
+            "roofline": rec["roofline"], "valu_roofline": rec["valu_roofline"], "parity": parity,
         }
         if args.workload == "cfg4":
             line["config"]["note"] = "one unit = one exchange = two DH_core evaluations"
-        if world == 1 and not args.no_cpu_baseline:
-            ms = codec.unpack_scalars(scalars_h)
-            out_h = out.cpu().numpy().view(np.uint64)
-            expected = codec.unpack_points(out_h)
-            if args.workload == "cfg2":
-                pts = codec.unpack_points(points.cpu().numpy().view(np.uint64))
-                line["cpu_baseline"] = cpu_baseline("mul_endo", list(zip(ms, pts)), None, expected, "MUL_endo(m, P)")
-            elif args.workload == "cfg3":
-                line["cpu_baseline"] = cpu_baseline("mul_windowed_fixed", ms, codec.unpack_table(extra_h), expected, "MUL_windowed(m, G, table)")
-            elif args.workload == "cfg4":
-                if bool(st1.any()) or bool(st2.any()):
-                    raise SystemExit("cfg4: unexpected DH failure status")
-                bs = codec.unpack_scalars(second_h)
-                line["cpu_baseline"] = cpu_baseline("dh_exchange", list(zip(ms, bs)), codec.unpack_table(extra_h), expected,
-                                                    "DH_endo(a, DH_endo(b, G, table))")
-            else:
-                pts = codec.unpack_points(points.cpu().numpy().view(np.uint64))
-                items = [(m, P if f else None) for m, P, f in zip(ms, pts, flags_h)]
-                line["cpu_baseline"] = cpu_baseline("mixed", items, codec.unpack_table(extra_h), expected, "50/50 fixed/variable MUL_endo")
-            line["cpu_baseline"]["c_restatement"] = c_port_baseline(
-                args.workload, scalars_h, second_h, points.cpu().numpy().view(np.uint64), extra_h, flags_h if args.workload == "cfg5" else None, out_h)
-            line["cpu_baseline"]["sample"] += "; plus %d edge-case scalar/point pairs (0, 1, 2, N-1, N, N+1, 2N, 2^255, 2^256-1 on +-G), exact" % edge_case_check(eng)
+        if gather is not None:
+            line["gather_ms"] = gather
+            line["config"]["gather"] = "results of all ranks gathered to rank 0 (fourq_amd.dist.gather_rows), untimed in `value`, median of 3"
+        if configs:
+            line["configs"] = configs
+        if world == 1 and not args.no_pcie and want is not None and args.workload in ("cfg2", "cfg3"):
+            line["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=20 if args.workload == "cfg2" else 3)
+        if not args.no_cpu_baseline and got is not None:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            sample = min(n, 1 << 16)
+            items, extra, what = cpu_items(args.workload, d, sample)
+            line["cpu_baseline"] = cpu_baseline(args.workload, items, extra, codec.unpack_points(got[:sample]), what)
+            line["cpu_baseline"]["c_restatement"] = {
+                "value": parity["c_oracle_units_per_s"], "unit": "scalar-mults/s", "threads": parity["c_oracle_threads"], "cores": host_cores(), "kind": "port",
+                "sample": "whole batch (%d units) via oracle/fourq_oracle.c (OpenMP), every output compared bit-exact with the GPU's" % n}
+            line["cpu_baseline"]["sample"] += "; plus %d edge-case scalar/point pairs (0, 1, 2, N-1, N, N+1, 2N, 2^255, 2^256-1 on +-G), exact" % edge_case_check(b.eng)
         print(json.dumps(line), flush=True)
-    eng.close()
+    b.eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
 
 
 if __name__ == "__main__":

@@ -11,6 +11,16 @@ OK, ERR_INVALID, ERR_NODEVICE, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
 DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
 DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3
 
+MAX_BATCH = 0xFFFFFF00
+BYTES_DECODE_BASE = 16
+
+
+class HostStats(ctypes.Structure):
+    """struct fourq_host_stats"""
+    _fields_ = [("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("h2d_bytes", c_uint64), ("d2h_bytes", c_uint64),
+                ("chunks", ctypes.c_uint32), ("pinned_in", c_int), ("pinned_out", c_int)]
+
+
 u64p = POINTER(c_uint64)
 u8p = POINTER(c_uint8)
 
@@ -24,6 +34,9 @@ PROTOTYPES = {
     "fourq_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "fourq_ctx_sync": (c_int, [c_void_p]),
     "fourq_ctx_lanes": (c_int, [c_void_p, POINTER(c_size_t)]),
+    "fourq_host_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "fourq_host_free": (c_int, [c_void_p, c_void_p]),
+    "fourq_ctx_host_stats": (c_int, [c_void_p, c_void_p]),
     "fourq_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "fourq_dev_free": (c_int, [c_void_p, c_void_p]),
     "fourq_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
@@ -44,6 +57,12 @@ PROTOTYPES = {
     "fourq_dh_windowed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_endo_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_windowed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_endo_bytes_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_windowed_bytes_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_endo_bytes_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_windowed_bytes_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_exchange_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_exchange_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_comb_table": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fourq_comb_mul_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_comb_mul_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
@@ -57,8 +76,8 @@ PROTOTYPES = {
 
 # enum fourq_prim
 PRIM = {
-    "FP_ADD": 0, "FP_SUB": 1, "FP_MUL": 2, "FP_SQR": 3, "FP_NEG": 4, "FP_INV": 5, "FP_INVSQRT": 6,
-    "FP2_ADD": 16, "FP2_SUB": 17, "FP2_MUL": 18, "FP2_SQR": 19, "FP2_NEG": 20, "FP2_CONJ": 21, "FP2_INV": 22,
+    "FP_ADD": 0, "FP_SUB": 1, "FP_MUL": 2, "FP_SQR": 3, "FP_NEG": 4, "FP_INV": 5, "FP_INVSQRT": 6, "FP_SELECT": 7,
+    "FP2_ADD": 16, "FP2_SUB": 17, "FP2_MUL": 18, "FP2_SQR": 19, "FP2_NEG": 20, "FP2_CONJ": 21, "FP2_INV": 22, "FP2_SELECT": 23,
     "PT_DBL": 32, "PT_ADD": 33, "PT_ADD_CORE": 34, "PT_R1TOR2": 35, "PT_R1TOR3": 36, "PT_R2TOR4": 37,
     "PT_TAU": 38, "PT_TAU_DUAL": 39, "PT_UPSILON": 40, "PT_CHI": 41, "PT_PHI": 42, "PT_PSI": 43,
     "PT_ON_CURVE": 44, "PT_COFACTOR392": 45, "PT_R1TOAFFINE": 46,

@@ -20,7 +20,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <functional>
 #include <new>
+#include <thread>
+#include <vector>
 
 #ifndef FQ_CHAIN
 #define FQ_CHAIN 0
@@ -141,6 +144,36 @@ __global__ __launch_bounds__(BLOCK) void decode_kernel(const u64* in, u64* affin
     status[i] = (uint8_t)st;
 }
 
+// Protocol step, last stage: encode the shared point and merge the per-stage verdicts into one status byte
+//   0 ok | FOURQ_DH_* of the DH stage | 16 + FOURQ_DECODE_* of the decode stage (which wins); out32 is zero unless 0.
+__global__ __launch_bounds__(BLOCK) void encode_status_kernel(const u64* affine, const uint8_t* st_decode, const uint8_t* st_dh,
+                                                              u64* out, uint8_t* status, u32 n) {
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t sd = st_decode[i], sh = st_dh[i];
+    const uint8_t st = sd ? (uint8_t)(16 + sd) : sh;
+    u64 w[4];
+    point_encode(load_fe2(affine + 8 * (size_t)i), load_fe2(affine + 8 * (size_t)i + 4), w);
+    if (st) w[0] = w[1] = w[2] = w[3] = 0;
+    uint4* dst = reinterpret_cast<uint4*>(out + 4 * (size_t)i);
+    dst[0] = make_uint4((u32)w[0], (u32)(w[0] >> 32), (u32)w[1], (u32)(w[1] >> 32));
+    dst[1] = make_uint4((u32)w[2], (u32)(w[2] >> 32), (u32)w[3], (u32)(w[3] >> 32));
+    status[i] = st;
+}
+// one affine point replicated n times (the public base of a batch of exchanges)
+__global__ __launch_bounds__(BLOCK) void broadcast_point_kernel(const u64* point, u64* out, u32 n) {
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)point[2 * k], (u32)(point[2 * k] >> 32), (u32)point[2 * k + 1], (u32)(point[2 * k + 1] >> 32));
+}
+// status of a two-stage exchange: the first failure of either half (the second half already zeroed its output)
+__global__ __launch_bounds__(BLOCK) void merge_status_kernel(const uint8_t* first, uint8_t* status, u32 n) {
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n && first[i]) status[i] = first[i];
+}
+
 // ---- primitives ----------------------------------------------------------------------------------
 FQ_DEV Fe<1> ld_fe(const u64* w) { return fe_unpack(w[0], w[1]); }
 template <int B> FQ_DEV void st_fe(u64* w, const Fe<B>& a) { fe_canon(a, w[0], w[1]); }
@@ -162,6 +195,20 @@ __global__ __launch_bounds__(64) void prim_kernel(int op, const u64* in, u64* ou
     case FOURQ_FP_NEG: st_fe(y, fe_neg(ld_fe(x))); break;
     case FOURQ_FP_INV: st_fe(y, fe_inv(fe_carry(ld_fe(x)))); break;
     case FOURQ_FP_INVSQRT: st_fe(y, fe_invsqrt(fe_carry(ld_fe(x)))); break;
+    case FOURQ_FP_SELECT:
+    case FOURQ_FP2_SELECT: {
+        // (mask * c) mod 2^128 = -c mod 2^128 for the reference's mask = 2^512 - 1; bit operations on the raw words,
+        // no reduction (the reference's select does none either)
+        const u64 m_lo = 0 - x[0], m_hi = ~x[1] + (x[0] == 0 ? 1 : 0);
+        const int parts = op == FOURQ_FP_SELECT ? 1 : 2;
+        const u64* a = x + 2;
+        const u64* b = x + 2 + 2 * parts;
+        for (int k = 0; k < parts; k++) {
+            y[2 * k] = b[2 * k] ^ (m_lo & (a[2 * k] ^ b[2 * k]));
+            y[2 * k + 1] = b[2 * k + 1] ^ (m_hi & (a[2 * k + 1] ^ b[2 * k + 1]));
+        }
+        break;
+    }
     case FOURQ_FP2_ADD: store_fe2(y, fe2_add(load_fe2(x), load_fe2(x + 4))); break;
     case FOURQ_FP2_SUB: store_fe2(y, fe2_sub(load_fe2(x), load_fe2(x + 4))); break;
     case FOURQ_FP2_MUL: store_fe2(y, fe2_mul(load_fe2(x), load_fe2(x + 4))); break;
@@ -232,6 +279,7 @@ __global__ __launch_bounds__(64) void prim_kernel(int op, const u64* in, u64* ou
 struct PrimShape { int op; size_t in_words, out_words; };
 const PrimShape PRIMS[] = {
     { FOURQ_FP_ADD, 4, 2 }, { FOURQ_FP_SUB, 4, 2 }, { FOURQ_FP_MUL, 4, 2 }, { FOURQ_FP_SQR, 4, 2 }, { FOURQ_FP_NEG, 4, 2 }, { FOURQ_FP_INV, 4, 2 }, { FOURQ_FP_INVSQRT, 4, 2 },
+    { FOURQ_FP_SELECT, 6, 2 }, { FOURQ_FP2_SELECT, 10, 4 },
     { FOURQ_FP2_ADD, 8, 4 }, { FOURQ_FP2_SUB, 8, 4 }, { FOURQ_FP2_MUL, 8, 4 }, { FOURQ_FP2_SQR, 8, 4 }, { FOURQ_FP2_NEG, 8, 4 },
     { FOURQ_FP2_CONJ, 8, 4 }, { FOURQ_FP2_INV, 8, 4 },
     { FOURQ_PT_DBL, 20, 20 }, { FOURQ_PT_ADD, 36, 20 }, { FOURQ_PT_ADD_CORE, 32, 20 }, { FOURQ_PT_R1TOR2, 20, 16 },
@@ -272,8 +320,18 @@ struct fourq_ctx {
     uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
     size_t proj_capacity = 0;
     int norm_k = -1;               // FOURQ_NORM_K: 0 = always invert per element, 2/4/8 = always batch; -1 = by batch size
-    void* stage = nullptr;         // staging for the host-pointer API
+    void* stage = nullptr;         // staging for the small host-pointer calls (tables, primitives)
     size_t stage_bytes = 0;
+    char* work = nullptr;          // intermediates of the protocol-level calls (decoded points, first-half results)
+    size_t work_bytes = 0;
+    // host-pointer batches: PIPE_SLOTS device slots (and pinned bounce slots for pageable callers) cycled through
+    // H2D copy -> kernels -> D2H copy on three streams
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipEvent_t in_done[3] = {}, kernels_done[3] = {}, out_done[3] = {};
+    std::vector<hipEvent_t> ticks;     // timing events around every copy of the last call
+    char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
+    char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
+    fourq_host_stats host_stats = {};
     char err[256] = { 0 };
 };
 
@@ -372,7 +430,7 @@ int stage_table(fourq_ctx* c, const uint64_t* table_host) {
 
 int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
             const u32* index, size_t n) {
-    if (!c || !scalars || !out || (!points && !table) || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !out || (!points && !table) || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(out) || !aligned16(points)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
@@ -386,7 +444,7 @@ int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
 
 int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
            uint8_t* status, size_t n) {
-    if (!c || !scalars || !points || !out || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !points || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(points) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
@@ -413,41 +471,161 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
     return FOURQ_OK;
 }
 
-// host-pointer wrappers: one staging buffer carved into [scalars | points | out | status]
+// ---- host-pointer batches ---------------------------------------------------------------------------------
+// The caller's arrays are cut into chunks of whole kernel generations; chunk k uses slot k mod PIPE_SLOTS and goes
+// H2D copy (stream copy_in) -> kernels (the context's stream) -> D2H copy (stream copy_out), the three stages of
+// consecutive chunks overlapping.  Arrays in pinned host memory (fourq_host_alloc, hipHostMalloc, torch pin_memory)
+// are copied by DMA straight from / to the caller's buffer; pageable arrays go through pinned bounce slots filled
+// and drained by a few host threads (a single memcpy stream would be slower than the link).
+constexpr int PIPE_SLOTS = 3;
+constexpr int PIPE_MAX_ARRAYS = 4;
+struct PipeArray {
+    const char* src;     // input array (host) or NULL
+    char* dst;           // output array (host) or NULL
+    size_t stride;       // bytes per element
+};
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+void host_copy(char* dst, const char* src, size_t bytes) {
+    constexpr size_t SLICE = 2u << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t threads = bytes / SLICE;
+    if (threads > 6) threads = 6;
+    if (hw && threads > hw) threads = hw;
+    if (threads <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> pool;
+    const size_t per = (bytes / threads + 63) & ~(size_t)63;
+    for (size_t t = 1; t < threads; t++) {
+        const size_t lo = t * per, hi = (t + 1 == threads) ? bytes : (t + 1) * per;
+        pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    memcpy(dst, src, per);
+    for (auto& th : pool) th.join();
+}
+int grow(fourq_ctx* c, char** buf, size_t* have, size_t want, bool pinned) {
+    if (want <= *have) return FOURQ_OK;
+    if (*buf) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, pinned ? hipHostFree(*buf) : hipFree(*buf));
+        *buf = nullptr; *have = 0;
+    }
+    void* p = nullptr;
+    HIP_TRY(c, pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want));
+    *buf = (char*)p; *have = want;
+    return FOURQ_OK;
+}
+int ensure_work(fourq_ctx* c, size_t bytes) { return grow(c, &c->work, &c->work_bytes, bytes + bytes / 4, false); }
+
+using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev, size_t m)>;
+
+int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, const ChunkLaunch& launch) {
+    if (n_in > PIPE_MAX_ARRAYS || n_out > PIPE_MAX_ARRAYS || chunk == 0) return FOURQ_ERR_INVALID;
+    if (chunk > n) chunk = n;
+    size_t off_in[PIPE_MAX_ARRAYS], off_out[PIPE_MAX_ARRAYS], slot = 0;
+    bool pin_in[PIPE_MAX_ARRAYS], pin_out[PIPE_MAX_ARRAYS], bounce = false;
+    for (int i = 0; i < n_in; i++) { off_in[i] = slot; slot += align256(chunk * in[i].stride); pin_in[i] = is_pinned(in[i].src); bounce |= !pin_in[i]; }
+    for (int i = 0; i < n_out; i++) { off_out[i] = slot; slot += align256(chunk * out[i].stride); pin_out[i] = is_pinned(out[i].dst); bounce |= !pin_out[i]; }
+    const size_t chunks = (n + chunk - 1) / chunk;
+    const int slots = chunks < (size_t)PIPE_SLOTS ? (int)chunks : PIPE_SLOTS;
+    int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
+    if (rc) return rc;
+    if (bounce && (rc = grow(c, &c->pipe_pin, &c->pipe_pin_bytes, slot * slots, true))) return rc;
+    while (c->ticks.size() < 4 * chunks) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreate(&e));
+        c->ticks.push_back(e);
+    }
+    fourq_host_stats st = {};
+    st.chunks = (uint32_t)chunks;
+    st.pinned_in = st.pinned_out = 1;
+    for (int i = 0; i < n_in; i++) st.pinned_in &= pin_in[i] ? 1 : 0;
+    for (int i = 0; i < n_out; i++) st.pinned_out &= pin_out[i] ? 1 : 0;
+
+    auto drain = [&](size_t k) -> int {          // chunk k has left the device: hand a pageable caller its bytes
+        const int b = (int)(k % slots);
+        HIP_TRY(c, hipEventSynchronize(c->out_done[b]));
+        const size_t off = k * chunk, m = n - off < chunk ? n - off : chunk;
+        for (int i = 0; i < n_out; i++)
+            if (!pin_out[i]) host_copy(out[i].dst + off * out[i].stride, c->pipe_pin + (size_t)b * slot + off_out[i], m * out[i].stride);
+        return FOURQ_OK;
+    };
+    for (size_t k = 0; k < chunks; k++) {
+        const int b = (int)(k % slots);
+        if (k >= (size_t)slots && (rc = drain(k - slots))) return rc;       // slot b is free again (device and bounce side)
+        const size_t off = k * chunk, m = n - off < chunk ? n - off : chunk;
+        char* dev = c->pipe_dev + (size_t)b * slot;
+        char* pin = bounce ? c->pipe_pin + (size_t)b * slot : nullptr;
+        char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
+        for (int i = 0; i < n_in; i++) {
+            din[i] = dev + off_in[i];
+            if (!pin_in[i]) host_copy(pin + off_in[i], in[i].src + off * in[i].stride, m * in[i].stride);
+        }
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * k], c->copy_in));
+        for (int i = 0; i < n_in; i++) {
+            const char* src = pin_in[i] ? in[i].src + off * in[i].stride : pin + off_in[i];
+            HIP_TRY(c, hipMemcpyAsync(din[i], src, m * in[i].stride, hipMemcpyHostToDevice, c->copy_in));
+            st.h2d_bytes += m * in[i].stride;
+        }
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 1], c->copy_in));
+        HIP_TRY(c, hipEventRecord(c->in_done[b], c->copy_in));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_done[b], 0));
+        for (int i = 0; i < n_out; i++) dout[i] = dev + off_out[i];
+        if ((rc = launch(din, dout, m))) return rc;
+        HIP_TRY(c, hipEventRecord(c->kernels_done[b], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->copy_out, c->kernels_done[b], 0));
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 2], c->copy_out));
+        for (int i = 0; i < n_out; i++) {
+            char* dst = pin_out[i] ? out[i].dst + off * out[i].stride : pin + off_out[i];
+            HIP_TRY(c, hipMemcpyAsync(dst, dout[i], m * out[i].stride, hipMemcpyDeviceToHost, c->copy_out));
+            st.d2h_bytes += m * out[i].stride;
+        }
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 3], c->copy_out));
+        HIP_TRY(c, hipEventRecord(c->out_done[b], c->copy_out));
+    }
+    for (size_t k = chunks > (size_t)slots ? chunks - slots : 0; k < chunks; k++)
+        if ((rc = drain(k))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < chunks; k++) {
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k], c->ticks[4 * k + 1]));
+        st.h2d_ms += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k + 2], c->ticks[4 * k + 3]));
+        st.d2h_ms += ms;
+    }
+    c->host_stats = st;
+    return FOURQ_OK;
+}
+
+// chunk of a host-pointer batch: whole generations of the kernels that will run it
+size_t pipe_chunk(const fourq_ctx* c, bool fused_route) { return fused_route ? c->lanes : c->lanes_w4; }
+
 int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out, size_t n) {
-    if (!c || !scalars || !out || (!points && !table)) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !out || (!points && !table) || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    size_t sb = n * 32, pb = points ? n * 160 : 0, ob = n * 160;
-    int rc = ensure_stage(c, sb + pb + ob);
-    if (rc) return rc;
-    char* base = (char*)c->stage;
-    HIP_TRY(c, hipMemcpyAsync(base, scalars, sb, hipMemcpyHostToDevice, c->stream));
-    if (points) HIP_TRY(c, hipMemcpyAsync(base + sb, points, pb, hipMemcpyHostToDevice, c->stream));
-    rc = mul_dev(c, algo, (const uint64_t*)base, points ? (const uint64_t*)(base + sb) : nullptr, table, (uint64_t*)(base + sb + pb), nullptr, n);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(out, base + sb + pb, ob, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return FOURQ_OK;
+    PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points, nullptr, 160 } };
+    PipeArray o[1] = { { nullptr, (char*)out, 160 } };
+    const bool fused = points && !takes_split_route(c, algo, false, n);
+    return run_pipeline(c, in, points ? 2 : 1, o, 1, n, pipe_chunk(c, fused), [&](char* const* di, char* const* dout, size_t m) {
+        return mul_dev(c, algo, (const uint64_t*)di[0], points ? (const uint64_t*)di[1] : nullptr, table, (uint64_t*)dout[0], nullptr, m);
+    });
 }
 int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
             uint8_t* status, size_t n) {
-    if (!c || !scalars || !points || !out || !status) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !points || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    size_t sb = n * 32, pb = n * 64, ob = n * 64, tb = (n + 15) / 16 * 16;
-    int rc = ensure_stage(c, sb + pb + ob + tb);
-    if (rc) return rc;
-    char* base = (char*)c->stage;
-    HIP_TRY(c, hipMemcpyAsync(base, scalars, sb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(base + sb, points, pb, hipMemcpyHostToDevice, c->stream));
-    rc = dh_dev(c, algo, (const uint64_t*)base, (const uint64_t*)(base + sb), table, (uint64_t*)(base + sb + pb),
-                (uint8_t*)(base + sb + pb + ob), n);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(out, base + sb + pb, ob, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(status, base + sb + pb + ob, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return FOURQ_OK;
+    PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points, nullptr, 64 } };
+    PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
+    const bool fused = !table && !takes_split_route(c, algo, true, n);
+    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, fused), [&](char* const* di, char* const* dout, size_t m) {
+        return dh_dev(c, algo, (const uint64_t*)di[0], (const uint64_t*)di[1], table, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
+    });
 }
 
 int table_host(fourq_ctx* c, int algo, const uint64_t* p_r1, uint64_t* table) {
@@ -500,6 +678,14 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
     do {
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
         c->stream = c->own_stream;
+        if (hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        if (hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
+        for (int i = 0; i < PIPE_SLOTS && rc == FOURQ_OK; i++) {
+            if (hipEventCreateWithFlags(&c->in_done[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->kernels_done[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess) rc = FOURQ_ERR_HIP;
+        }
+        if (rc) break;
         // resident blocks per CU of the fused variable-base kernels (they own the per-lane scratch slots)
         int occ = 8, o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<ENDO, FUSED, false>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
@@ -542,6 +728,17 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->comb_limbs) (void)hipFree(c->comb_limbs);
     if (c->comb_packed) (void)hipFree(c->comb_packed);
     if (c->stage) (void)hipFree(c->stage);
+    if (c->work) (void)hipFree(c->work);
+    if (c->pipe_dev) (void)hipFree(c->pipe_dev);
+    if (c->pipe_pin) (void)hipHostFree(c->pipe_pin);
+    for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
+    for (int i = 0; i < PIPE_SLOTS; i++) {
+        if (c->in_done[i]) (void)hipEventDestroy(c->in_done[i]);
+        if (c->kernels_done[i]) (void)hipEventDestroy(c->kernels_done[i]);
+        if (c->out_done[i]) (void)hipEventDestroy(c->out_done[i]);
+    }
+    if (c->copy_in) (void)hipStreamDestroy(c->copy_in);
+    if (c->copy_out) (void)hipStreamDestroy(c->copy_out);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return FOURQ_OK;
@@ -549,7 +746,14 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
 
 FQ_API int fourq_ctx_set_stream(fourq_ctx* c, void* hip_stream) {
     if (!c) return FOURQ_ERR_INVALID;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (next != c->stream) {
+        // the staged fixed-base / comb tables were unpacked by launches on the old stream: nothing orders the new
+        // stream behind them, so they are staged again (1 KiB / 7.5 KiB) by the next call that needs them
+        c->table_staged = false;
+        c->comb_staged = false;
+    }
+    c->stream = next;
     return FOURQ_OK;
 }
 FQ_API int fourq_ctx_sync(fourq_ctx* c) {
@@ -621,7 +825,7 @@ FQ_API int fourq_mul_windowed_fixed_batch_dev(fourq_ctx* c, const uint64_t* s, c
 
 FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint8_t* flags,
                                           const uint64_t* table, uint64_t* o, size_t n) {
-    if (!c || !s || !p || !flags || !table || !o || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!c || !s || !p || !flags || !table || !o || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(s) || !aligned16(p) || !aligned16(o)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
@@ -652,22 +856,14 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
 }
 FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint8_t* flags,
                                       const uint64_t* table, uint64_t* o, size_t n) {
-    if (!c || !s || !p || !flags || !table || !o) return FOURQ_ERR_INVALID;
+    if (!c || !s || !p || !flags || !table || !o || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    size_t sb = n * 32, pb = n * 160, ob = n * 160, fb = (n + 15) / 16 * 16;
-    int rc = ensure_stage(c, sb + pb + ob + fb);
-    if (rc) return rc;
-    char* base = (char*)c->stage;
-    HIP_TRY(c, hipMemcpyAsync(base, s, sb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(base + sb, p, pb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(base + sb + pb + ob, flags, n, hipMemcpyHostToDevice, c->stream));
-    rc = fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)base, (const uint64_t*)(base + sb), (const uint8_t*)(base + sb + pb + ob),
-                                        table, (uint64_t*)(base + sb + pb), n);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(o, base + sb + pb, ob, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return FOURQ_OK;
+    PipeArray in[3] = { { (const char*)s, nullptr, 32 }, { (const char*)p, nullptr, 160 }, { (const char*)flags, nullptr, 1 } };
+    PipeArray out[1] = { { nullptr, (char*)o, 160 } };
+    return run_pipeline(c, in, 3, out, 1, n, c->split_chunk, [&](char* const* di, char* const* dout, size_t m) {
+        return fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], (const uint8_t*)di[2], table, (uint64_t*)dout[0], m);
+    });
 }
 
 FQ_API int fourq_dh_endo_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
@@ -696,7 +892,7 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
     return FOURQ_OK;
 }
 FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
-    if (!c || !scalars || !comb || !out || !status || n > 0xffffffffu) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !comb || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
@@ -718,24 +914,18 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     return FOURQ_OK;
 }
 FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
-    if (!c || !scalars || !comb || !out || !status) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !comb || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    size_t sb = n * 32, ob = n * 64;
-    int rc = ensure_stage(c, sb + ob + n + 16);
-    if (rc) return rc;
-    char* base = (char*)c->stage;
-    HIP_TRY(c, hipMemcpyAsync(base, scalars, sb, hipMemcpyHostToDevice, c->stream));
-    rc = fourq_comb_mul_batch_dev(c, (const uint64_t*)base, comb, (uint64_t*)(base + sb), (uint8_t*)(base + sb + ob), n);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(out, base + sb, ob, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(status, base + sb + ob, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return FOURQ_OK;
+    PipeArray in[1] = { { (const char*)scalars, nullptr, 32 } };
+    PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
+    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+        return fourq_comb_mul_batch_dev(c, (const uint64_t*)di[0], comb, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
+    });
 }
 
 FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {
-    if (!c || !affine || !out32 || n > 0xffffffffu || !aligned16(affine) || !aligned16(out32)) return FOURQ_ERR_INVALID;
+    if (!c || !affine || !out32 || n > FOURQ_MAX_BATCH || !aligned16(affine) || !aligned16(out32)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, affine, (u64*)out32, (u32)n);
@@ -743,7 +933,7 @@ FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t*
     return FOURQ_OK;
 }
 FQ_API int fourq_decode_batch_dev(fourq_ctx* c, const uint8_t* in32, uint64_t* affine, uint8_t* status, size_t n) {
-    if (!c || !in32 || !affine || !status || n > 0xffffffffu || !aligned16(in32) || !aligned16(affine)) return FOURQ_ERR_INVALID;
+    if (!c || !in32 || !affine || !status || n > FOURQ_MAX_BATCH || !aligned16(in32) || !aligned16(affine)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)in32, affine, status, (u32)n);
@@ -751,32 +941,127 @@ FQ_API int fourq_decode_batch_dev(fourq_ctx* c, const uint8_t* in32, uint64_t* a
     return FOURQ_OK;
 }
 FQ_API int fourq_encode_batch(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {
-    if (!c || !affine || !out32) return FOURQ_ERR_INVALID;
+    if (!c || !affine || !out32 || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    int rc = ensure_stage(c, n * 96);
-    if (rc) return rc;
-    char* base = (char*)c->stage;
-    HIP_TRY(c, hipMemcpyAsync(base, affine, n * 64, hipMemcpyHostToDevice, c->stream));
-    rc = fourq_encode_batch_dev(c, (const uint64_t*)base, (uint8_t*)(base + n * 64), n);
-    if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(out32, base + n * 64, n * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return FOURQ_OK;
+    PipeArray in[1] = { { (const char*)affine, nullptr, 64 } };
+    PipeArray o[1] = { { nullptr, (char*)out32, 32 } };
+    return run_pipeline(c, in, 1, o, 1, n, 4 * c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+        return fourq_encode_batch_dev(c, (const uint64_t*)di[0], (uint8_t*)dout[0], m);
+    });
 }
 FQ_API int fourq_decode_batch(fourq_ctx* c, const uint8_t* in32, uint64_t* affine, uint8_t* status, size_t n) {
-    if (!c || !in32 || !affine || !status) return FOURQ_ERR_INVALID;
+    if (!c || !in32 || !affine || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    int rc = ensure_stage(c, n * 97 + 16);
+    PipeArray in[1] = { { (const char*)in32, nullptr, 32 } };
+    PipeArray o[2] = { { nullptr, (char*)affine, 64 }, { nullptr, (char*)status, 1 } };
+    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+        return fourq_decode_batch_dev(c, (const uint8_t*)di[0], (uint64_t*)dout[0], (uint8_t*)dout[1], m);
+    });
+}
+
+// ---- protocol-level calls: every intermediate stays on the device -------------------------------------------
+// decode -> DH_<algo> -> encode (draft-ladd-cfrg-4q.md:707-723; curve4q.py:49-96, :446-462, :41-46)
+static int dh_bytes_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint8_t* keys32, const uint64_t* table, uint8_t* out32,
+                        uint8_t* status, size_t n) {
+    if (!c || !scalars || !keys32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!aligned16(scalars) || !aligned16(keys32) || !aligned16(out32)) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    const size_t nb = align256(n);
+    int rc = ensure_work(c, 2 * n * 64 + 2 * nb);
     if (rc) return rc;
-    char* base = (char*)c->stage;
-    HIP_TRY(c, hipMemcpyAsync(base, in32, n * 32, hipMemcpyHostToDevice, c->stream));
-    rc = fourq_decode_batch_dev(c, (const uint8_t*)base, (uint64_t*)(base + n * 32), (uint8_t*)(base + n * 96), n);
+    uint64_t* pts = (uint64_t*)c->work;                       // decoded public keys
+    uint64_t* shared = (uint64_t*)(c->work + n * 64);         // affine shared points
+    uint8_t* st_decode = (uint8_t*)(c->work + 2 * n * 64);
+    uint8_t* st_dh = st_decode + nb;
+    if ((rc = fourq_decode_batch_dev(c, keys32, pts, st_decode, n))) return rc;
+    if ((rc = dh_dev(c, algo, scalars, pts, table, shared, st_dh, n))) return rc;    // an undecodable key is (0, 0): rejected again here
+    hipLaunchKernelGGL(encode_status_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, shared, st_decode, st_dh,
+                       (u64*)out32, status, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+static int dh_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint8_t* keys32, const uint64_t* table, uint8_t* out32,
+                         uint8_t* status, size_t n) {
+    if (!c || !scalars || !keys32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)keys32, nullptr, 32 } };
+    PipeArray o[2] = { { nullptr, (char*)out32, 32 }, { nullptr, (char*)status, 1 } };
+    const bool fused = !table && !takes_split_route(c, algo, true, n);
+    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, fused), [&](char* const* di, char* const* dout, size_t m) {
+        return dh_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], table, (uint8_t*)dout[0], (uint8_t*)dout[1], m);
+    });
+}
+FQ_API int fourq_dh_endo_bytes_batch_dev(fourq_ctx* c, const uint64_t* s, const uint8_t* k, const uint64_t* t, uint8_t* o, uint8_t* st, size_t n) {
+    return dh_bytes_dev(c, ENDO, s, k, t, o, st, n);
+}
+FQ_API int fourq_dh_windowed_bytes_batch_dev(fourq_ctx* c, const uint64_t* s, const uint8_t* k, const uint64_t* t, uint8_t* o, uint8_t* st, size_t n) {
+    return dh_bytes_dev(c, WINDOWED, s, k, t, o, st, n);
+}
+FQ_API int fourq_dh_endo_bytes_batch(fourq_ctx* c, const uint64_t* s, const uint8_t* k, const uint64_t* t, uint8_t* o, uint8_t* st, size_t n) {
+    return dh_bytes_host(c, ENDO, s, k, t, o, st, n);
+}
+FQ_API int fourq_dh_windowed_bytes_batch(fourq_ctx* c, const uint64_t* s, const uint8_t* k, const uint64_t* t, uint8_t* o, uint8_t* st, size_t n) {
+    return dh_bytes_host(c, WINDOWED, s, k, t, o, st, n);
+}
+
+// dh_exchange: DH_endo(a_i, DH_endo(b_i, base [, table392])) with the first half's public keys kept on the device
+FQ_API int fourq_dh_exchange_batch_dev(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* base_affine, const uint64_t* table392,
+                                       uint64_t* out, uint8_t* status, size_t n) {
+    if (!c || !a || !b || !base_affine || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    const size_t nb = align256(n);
+    int rc = ensure_work(c, 2 * n * 64 + nb + 256);
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpyAsync(affine, base + n * 32, n * 64, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(status, base + n * 96, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t* base = (uint64_t*)c->work;                      // the base point, once per exchange
+    uint64_t* mid = (uint64_t*)(c->work + n * 64);            // DH(b_i, base): the public keys
+    uint8_t* st_first = (uint8_t*)(c->work + 2 * n * 64);
+    uint64_t* one = (uint64_t*)(st_first + nb);
+    HIP_TRY(c, hipMemcpyAsync(one, base_affine, 64, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(broadcast_point_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, one, base, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    if ((rc = dh_dev(c, ENDO, b, base, table392, mid, st_first, n))) return rc;
+    if ((rc = dh_dev(c, ENDO, a, mid, nullptr, out, status, n))) return rc;
+    hipLaunchKernelGGL(merge_status_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, st_first, status, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* base_affine, const uint64_t* table392,
+                                   uint64_t* out, uint8_t* status, size_t n) {
+    if (!c || !a || !b || !base_affine || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    uint64_t base_copy[8];
+    memcpy(base_copy, base_affine, sizeof base_copy);         // the H2D copy of the base is asynchronous: keep a stable source
+    PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
+    PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
+    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+        return fourq_dh_exchange_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], base_copy, table392, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
+    });
+}
+
+// ---- pinned host memory and transfer statistics of the host-pointer calls ---------------------------------------
+FQ_API int fourq_host_alloc(fourq_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return FOURQ_OK;
+}
+FQ_API int fourq_host_free(fourq_ctx* c, void* ptr) {
+    if (!c) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipHostFree(ptr));
+    return FOURQ_OK;
+}
+FQ_API int fourq_ctx_host_stats(const fourq_ctx* c, fourq_host_stats* out) {
+    if (!c || !out) return FOURQ_ERR_INVALID;
+    *out = c->host_stats;
     return FOURQ_OK;
 }
 

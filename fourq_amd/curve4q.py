@@ -240,11 +240,19 @@ def _dh(kind, m, P, table):
 
 
 def DH_core(m, P, mul, table=None):
+    """curve4q.py:446-462.  The two multiplications of the reference run as one fused DH kernel; any other callable
+    `mul(m, Q, table=...)` gets the reference's own composition, each step on the GPU through the primitives."""
     if mul is MUL_windowed:
         return _dh("windowed", m, P, table)
     if mul is MUL_endo:
         return _dh("endo", m, P, table)
-    raise ValueError("DH_core: mul must be MUL_windowed or MUL_endo")
+    if not PointOnCurve(P):
+        raise Exception(_MSG[1])
+    Q = _prim_pt("PT_COFACTOR392", (P[0], P[1]))           # the DBL/ADD chain of curve4q.py:450-455
+    Q = R1toAffine(mul(m, Q, table=table))
+    if Q == (Ox, Oy):
+        raise Exception(_MSG[2])
+    return Q
 
 
 def DH_windowed(m, P, table=None):

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import PRIM, FourQError, check
+from ._lib import PRIM, FourQError, HostStats, check
 
 
 def _ptr(x):
@@ -45,9 +45,14 @@ class Engine:
         if stream is not None:
             self.set_stream(stream)
 
+        self._pinned = {}            # address -> size of the pinned host blocks handed out by host_empty()
+
     # ---- lifetime --------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None):
+            for addr in list(getattr(self, "_pinned", {})):
+                self._lib.fourq_host_free(self._ctx, ctypes.c_void_p(addr))
+            self._pinned = {}
             self._lib.fourq_ctx_destroy(self._ctx)
             self._ctx = None
 
@@ -69,6 +74,42 @@ class Engine:
 
     def sync(self):
         self._ck(self._lib.fourq_ctx_sync(self._ctx))
+
+    # ---- pinned host memory (the fast path of the host-pointer calls) ---------------------------
+    def host_empty(self, shape, dtype=np.uint64):
+        """Uninitialised numpy array in pinned host memory (fourq_host_alloc): the host-array entry points move such
+        arrays by DMA without a bounce copy.  The memory belongs to the engine and is released by close() (or
+        host_free); arrays must not be used after that."""
+        dt = np.dtype(dtype)
+        count = int(np.prod(shape, dtype=np.int64)) if np.ndim(shape) else int(shape)
+        nbytes = max(16, count * dt.itemsize)
+        ptr = ctypes.c_void_p()
+        self._ck(self._lib.fourq_host_alloc(self._ctx, nbytes, ctypes.byref(ptr)))
+        self._pinned[ptr.value] = nbytes
+        buf = (ctypes.c_char * nbytes).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+    def host_array(self, a, dtype=None):
+        """Copy of `a` in pinned host memory."""
+        a = np.asarray(a, dtype=dtype)
+        out = self.host_empty(a.shape, a.dtype)
+        out[...] = a
+        return out
+
+    def host_free(self, a):
+        addr = a.ctypes.data
+        if addr in self._pinned:
+            self._ck(self._lib.fourq_host_free(self._ctx, ctypes.c_void_p(addr)))
+            del self._pinned[addr]
+
+    def host_stats(self):
+        """Transfer statistics of the last host-array call: dict with h2d/d2h milliseconds, bytes and GB/s."""
+        st = HostStats()
+        self._ck(self._lib.fourq_ctx_host_stats(self._ctx, ctypes.byref(st)))
+        d = {f: getattr(st, f) for f, _ in HostStats._fields_}
+        d["gbs_h2d"] = st.h2d_bytes / st.h2d_ms / 1e6 if st.h2d_ms > 0 else None
+        d["gbs_d2h"] = st.d2h_bytes / st.d2h_ms / 1e6 if st.d2h_ms > 0 else None
+        return d
 
     @property
     def lanes(self):
@@ -92,28 +133,32 @@ class Engine:
         return self._table(self._lib.fourq_table_windowed, p_r1)
 
     # ---- scalar multiplication (host arrays) -----------------------------------------------
-    def _mul(self, fn, scalars, second, second_cols):
+    def _mul(self, fn, scalars, second, second_cols, out=None):
         s = _host(scalars, 4)
         b = _host(second, second_cols)
         if second_cols == 20 and len(b) != len(s):
             raise ValueError("scalars and points differ in length")
         if second_cols is None and b.size != 128:
             raise ValueError("a table is 128 words")
-        out = np.empty((len(s), 20), dtype=np.uint64)
+        if out is None:
+            out = np.empty((len(s), 20), dtype=np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (len(s), 20) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (n, 20) uint64 array")
         self._ck(fn(self._ctx, _ptr(s), _ptr(b), _ptr(out), len(s)))
         return out
 
-    def mul_endo(self, scalars, points_r1):
-        return self._mul(self._lib.fourq_mul_endo_batch, scalars, points_r1, 20)
+    # `out`: optional preallocated result array, e.g. from host_empty() (pinned: no bounce copy on the way back)
+    def mul_endo(self, scalars, points_r1, out=None):
+        return self._mul(self._lib.fourq_mul_endo_batch, scalars, points_r1, 20, out)
 
-    def mul_windowed(self, scalars, points_r1):
-        return self._mul(self._lib.fourq_mul_windowed_batch, scalars, points_r1, 20)
+    def mul_windowed(self, scalars, points_r1, out=None):
+        return self._mul(self._lib.fourq_mul_windowed_batch, scalars, points_r1, 20, out)
 
-    def mul_endo_fixed(self, scalars, table):
-        return self._mul(self._lib.fourq_mul_endo_fixed_batch, scalars, table, None)
+    def mul_endo_fixed(self, scalars, table, out=None):
+        return self._mul(self._lib.fourq_mul_endo_fixed_batch, scalars, table, None, out)
 
-    def mul_windowed_fixed(self, scalars, table):
-        return self._mul(self._lib.fourq_mul_windowed_fixed_batch, scalars, table, None)
+    def mul_windowed_fixed(self, scalars, table, out=None):
+        return self._mul(self._lib.fourq_mul_windowed_fixed_batch, scalars, table, None, out)
 
     def mul_endo_mixed(self, scalars, points_r1, flags, table):
         s, p = _host(scalars, 4), _host(points_r1, 20)
@@ -145,17 +190,29 @@ class Engine:
         return self._dh(self._lib.fourq_dh_windowed_batch, scalars, points_affine, table)
 
     def dh_exchange(self, a_scalars, b_scalars, base_affine, table392=None):
-        """One exchange per row: DH_endo(a_i, DH_endo(b_i, base)) (curve4q.py:731).
+        """One exchange per row: DH_endo(a_i, DH_endo(b_i, base)) (curve4q.py:731), the first half's
+        public keys staying on the device (fourq_dh_exchange_batch).
 
         `table392` = table_endo([392]base) makes the first half fixed-base.  Returns (affine, status):
         status is the first failure of either half."""
-        b = _host(b_scalars, 4)
-        base = np.broadcast_to(_host(base_affine, None).reshape(1, 8), (len(b), 8))
-        mid, st1 = self.dh_endo(b, base, table392)
-        out, st2 = self.dh_endo(a_scalars, mid)
-        status = np.where(st1 != 0, st1, st2).astype(np.uint8)
-        out[status != 0] = 0
+        a, b = _host(a_scalars, 4), _host(b_scalars, 4)
+        if len(a) != len(b):
+            raise ValueError("the two scalar arrays differ in length")
+        base = _host(base_affine, None).ravel()
+        if base.size != 8:
+            raise ValueError("an affine point is 8 words")
+        t = None if table392 is None else _host(table392, None).ravel()
+        if t is not None and t.size != 128:
+            raise ValueError("a table is 128 words")
+        out = np.empty((len(a), 8), dtype=np.uint64)
+        status = np.empty(len(a), dtype=np.uint8)
+        self._ck(self._lib.fourq_dh_exchange_batch(self._ctx, _ptr(a), _ptr(b), _ptr(base), _ptr(t), _ptr(out), _ptr(status), len(a)))
         return out, status
+
+    def dh_exchange_dev(self, a_scalars, b_scalars, base_affine_host, table392_host, out_affine, status, n):
+        base = _host(base_affine_host, None).ravel()
+        t = None if table392_host is None else _host(table392_host, None).ravel()
+        self._ck(self._lib.fourq_dh_exchange_batch_dev(self._ctx, _ptr(a_scalars), _ptr(b_scalars), _ptr(base), _ptr(t), _ptr(out_affine), _ptr(status), n))
 
     # ---- fixed-base comb (80-point table; affine outputs only) ------------------------------------
     def comb_table(self, p_r1):
@@ -200,13 +257,24 @@ class Engine:
 
     def dh_bytes(self, scalars, public_keys32, kind="endo", table=None):
         """The protocol step of draft-ladd-cfrg-4q section "Diffie-Hellman": decode each 32-byte public key, DH_<kind> with
-        the scalar, encode the shared point.  Returns ((n, 32) uint8, status): 0 ok, 1/2 as DH_*, 16 + decode status."""
-        pts, dst = self.decode(public_keys32)
-        out, st = (self.dh_endo if kind == "endo" else self.dh_windowed)(scalars, pts, table)
-        status = np.where(dst != 0, 16 + dst, st).astype(np.uint8)
-        enc = self.encode(out)
-        enc[status != 0] = 0
-        return enc, status
+        the scalar, encode the shared point -- one call, intermediates stay on the GPU (fourq_dh_*_bytes_batch).
+        Returns ((n, 32) uint8, status): 0 ok, 1/2 as DH_*, 16 + decode status."""
+        s, k = _host(scalars, 4), _host(public_keys32, 32, np.uint8)
+        if len(s) != len(k):
+            raise ValueError("scalars and keys differ in length")
+        t = None if table is None else _host(table, None).ravel()
+        if t is not None and t.size != 128:
+            raise ValueError("a table is 128 words")
+        out = np.empty((len(s), 32), dtype=np.uint8)
+        status = np.empty(len(s), dtype=np.uint8)
+        fn = self._lib.fourq_dh_endo_bytes_batch if kind == "endo" else self._lib.fourq_dh_windowed_bytes_batch
+        self._ck(fn(self._ctx, _ptr(s), _ptr(k), _ptr(t), _ptr(out), _ptr(status), len(s)))
+        return out, status
+
+    def dh_bytes_dev(self, scalars, keys32, table_host, out32, status, n, kind="endo"):
+        t = None if table_host is None else _host(table_host, None).ravel()
+        fn = self._lib.fourq_dh_endo_bytes_batch_dev if kind == "endo" else self._lib.fourq_dh_windowed_bytes_batch_dev
+        self._ck(fn(self._ctx, _ptr(scalars), _ptr(keys32), _ptr(t), _ptr(out32), _ptr(status), n))
 
     def encode_dev(self, points_affine, out32, n):
         self._ck(self._lib.fourq_encode_batch_dev(self._ctx, _ptr(points_affine), _ptr(out32), n))

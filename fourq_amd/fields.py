@@ -16,6 +16,23 @@ def _fp(op, x, y=0):
     return int(out[0]) | (int(out[1]) << 64)
 
 
+def _raw128(x):
+    x = int(x)
+    if x < 0 or x >> 128:
+        raise ValueError("select takes values in [0, 2^128)")
+    return (x & codec.M64, x >> 64)
+
+
+def _select(op, c, parts_x, parts_y):
+    """GFp.select / GFp2.select on the device: y ^ ((mask * c) & (x ^ y)) on raw 128-bit words (fields.py:59-64)."""
+    words = [*_raw128(int(c) % (1 << 128))]
+    for v in (*parts_x, *parts_y):
+        words.extend(_raw128(v))
+    out = default_engine().prim(op, np.array([words], dtype=np.uint64))[0]
+    vals = [int(out[i]) | (int(out[i + 1]) << 64) for i in range(0, len(out), 2)]
+    return vals
+
+
 def _fp2(op, a, b=(0, 0)):
     row = codec.pack_fp2s([a, b]).reshape(1, 8)
     return codec.unpack_fp2s(default_engine().prim(op, row)[0])[0]
@@ -62,8 +79,8 @@ class GFp:
         return int.from_bytes(bytes(x), "little")
 
     @staticmethod
-    def select(c, x, y):                               # fields.py:60 -- host-side: no arithmetic involved
-        return x if c == 1 else y
+    def select(c, x, y):                               # fields.py:60 (x if c == 1, y if c == 0; masked XOR on the device)
+        return _select("FP_SELECT", c, (x,), (y,))[0]
 
 
 class GFp2:
@@ -113,4 +130,4 @@ class GFp2:
 
     @staticmethod
     def select(c, x, y):                               # fields.py:237
-        return x if c == 1 else y
+        return tuple(_select("FP2_SELECT", c, x, y))

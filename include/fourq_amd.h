@@ -25,11 +25,12 @@
  *
  * A context owns device scratch (per-lane look-up tables, staging) that its launches reuse in stream order:
  * let the current stream's work finish (fourq_ctx_sync or the caller's own synchronisation) before handing the
- * context another stream with fourq_ctx_set_stream.
+ * context another stream with fourq_ctx_set_stream (the staged fixed-base tables are re-staged on the new stream).
  *
  * Pointer flavours: functions ending in _dev take DEVICE pointers, enqueue on the context's
  * stream and return without synchronising (use fourq_ctx_sync or the caller's stream).  The same
- * names without _dev take HOST pointers and are synchronous (H2D copy, kernel, D2H copy).
+ * names without _dev take HOST pointers and are synchronous (H2D copy, kernel, D2H copy, pipelined over chunks of
+ * the batch on three streams; see fourq_host_alloc for the fast path).
  * Device arrays are read and written as 16-byte vectors: every array pointer handed to a _dev function must be
  * 16-byte aligned (FOURQ_ERR_INVALID otherwise; hipMalloc / fourq_dev_alloc / torch allocations are).  Host
  * pointers need no particular alignment.
@@ -56,6 +57,9 @@ extern "C" {
 #define FOURQ_DH_NOT_ON_CURVE 1
 #define FOURQ_DH_NEUTRAL 2
 
+/* largest batch any entry point accepts (the kernels' 32-bit element counters round n up to whole 256-lane blocks) */
+#define FOURQ_MAX_BATCH 0xffffff00u
+
 #define FOURQ_SCALAR_WORDS 4
 #define FOURQ_AFFINE_WORDS 8
 #define FOURQ_R1_WORDS 20
@@ -77,6 +81,21 @@ int fourq_ctx_set_stream(fourq_ctx *ctx, void *hip_stream);
 int fourq_ctx_sync(fourq_ctx *ctx);
 /* Resident lanes the ladder kernels are launched with (scratch is sized for this many). */
 int fourq_ctx_lanes(const fourq_ctx *ctx, size_t *lanes);
+
+/* Pinned (page-locked) host memory.  The host-pointer batch calls cut their arrays into chunks and overlap the
+ * H2D copy, the kernels and the D2H copy of consecutive chunks; arrays that live in pinned memory (from here, from
+ * hipHostMalloc or from torch's pin_memory) are moved by DMA straight from / to the caller's buffer at the link's
+ * rate, pageable arrays take an extra pass through pinned bounce buffers filled by host threads. */
+int fourq_host_alloc(fourq_ctx *ctx, size_t bytes, void **out);
+int fourq_host_free(fourq_ctx *ctx, void *ptr);
+/* transfer statistics of the context's last host-pointer batch call */
+typedef struct fourq_host_stats {
+    double h2d_ms, d2h_ms;          /* summed durations of the chunk copies, HIP events on the copy streams */
+    uint64_t h2d_bytes, d2h_bytes;
+    uint32_t chunks;
+    int pinned_in, pinned_out;      /* 1: every input / output array was pinned (no bounce copy) */
+} fourq_host_stats;
+int fourq_ctx_host_stats(const fourq_ctx *ctx, fourq_host_stats *out);
 
 /* Plain device-memory helpers so that a host program without a HIP binding can use the _dev API. */
 int fourq_dev_alloc(fourq_ctx *ctx, size_t bytes, void **out);
@@ -124,6 +143,28 @@ int fourq_dh_endo_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint6
 int fourq_dh_windowed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, const uint64_t *table,
                                 uint64_t *out_affine, uint8_t *status, size_t n);
 
+/* ---- the protocol step on the device: 32-byte public keys in, 32-byte shared secrets out -----------------------
+ * out32[i] = encode(DH_<algo>(m_i, decode(keys32[i]) [, table]))   draft-ladd-cfrg-4q.md:707-723;
+ * curve4q.py:49-96 (decode), :446-462 (DH_core), :41-46 (encode).  Decoded points and shared points never leave the
+ * GPU.  status[i]: 0 ok; FOURQ_DH_NOT_ON_CURVE / FOURQ_DH_NEUTRAL from the DH stage; 16 + FOURQ_DECODE_* when the
+ * key does not decode (takes precedence).  out32[i] is all zero unless status[i] == 0. */
+#define FOURQ_BYTES_DECODE_BASE 16
+int fourq_dh_endo_bytes_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *keys32, const uint64_t *table,
+                              uint8_t *out32, uint8_t *status, size_t n);
+int fourq_dh_windowed_bytes_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *keys32, const uint64_t *table,
+                                  uint8_t *out32, uint8_t *status, size_t n);
+int fourq_dh_endo_bytes_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *keys32, const uint64_t *table,
+                                  uint8_t *out32, uint8_t *status, size_t n);
+int fourq_dh_windowed_bytes_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *keys32, const uint64_t *table,
+                                      uint8_t *out32, uint8_t *status, size_t n);
+/* One exchange per element: out[i] = DH_endo(a_i, DH_endo(b_i, base [, table392])) -- the pattern of curve4q.py:731
+ * (BASELINE.json "dh_exchange"); `base_affine` (8 words) and `table392` = table_endo([392]base) or NULL are HOST
+ * pointers in both flavours.  The first half's results stay on the device.  status[i]: first failure of either half. */
+int fourq_dh_exchange_batch(fourq_ctx *ctx, const uint64_t *a_scalars, const uint64_t *b_scalars, const uint64_t *base_affine,
+                            const uint64_t *table392, uint64_t *out_affine, uint8_t *status, size_t n);
+int fourq_dh_exchange_batch_dev(fourq_ctx *ctx, const uint64_t *a_scalars, const uint64_t *b_scalars, const uint64_t *base_affine,
+                                const uint64_t *table392, uint64_t *out_affine, uint8_t *status, size_t n);
+
 /* ---- point compression: encode(X, Y) curve4q.py:41, decode(B) curve4q.py:49 -----------------------
  * 32 bytes per point: y0 | y1 little-endian, sign(x) in the top bit of the last byte.  decode reports, per
  * element, the exception the reference would raise; out_affine[i] is all zero unless status[i] == 0. */
@@ -157,6 +198,9 @@ enum fourq_prim {
     /* GFp, fields.py:29-106: in = a[2] b[2] */
     FOURQ_FP_ADD = 0, FOURQ_FP_SUB = 1, FOURQ_FP_MUL = 2, FOURQ_FP_SQR = 3, FOURQ_FP_NEG = 4, FOURQ_FP_INV = 5,
     FOURQ_FP_INVSQRT = 6,       /* fields.py:110 */
+    /* GFp.select(c, x, y) fields.py:59-64, GFp2.select fields.py:236-238: in = c[2] x y; raw 128-bit words,
+     * y ^ ((mask * c) & (x ^ y)) with the reference's mask = 2^512 - 1, no reduction (as the reference) */
+    FOURQ_FP_SELECT = 7, FOURQ_FP2_SELECT = 23,
     /* GFp2, fields.py:156-199: in = a[4] b[4] */
     FOURQ_FP2_ADD = 16, FOURQ_FP2_SUB = 17, FOURQ_FP2_MUL = 18, FOURQ_FP2_SQR = 19, FOURQ_FP2_NEG = 20,
     FOURQ_FP2_CONJ = 21, FOURQ_FP2_INV = 22,

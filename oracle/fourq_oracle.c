@@ -421,3 +421,13 @@ EXPORT int fqo_num_threads(void) {
     return 1;
 #endif
 }
+/* The environment variable OMP_NUM_THREADS is read once, when libgomp is first loaded (numpy / torch usually got
+ * there first), so a caller that wants a given thread count sets it through the library. */
+EXPORT void fqo_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

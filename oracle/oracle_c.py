@@ -32,6 +32,8 @@ def lib():
         _lib.fqo_dh_batch.argtypes = [i, vp, vp, vp, vp, vp, sz]
         _lib.fqo_decompose_batch.argtypes = [vp, vp, sz]
         _lib.fqo_num_threads.restype = ctypes.c_int
+        _lib.fqo_set_num_threads.argtypes = [i]
+        _lib.fqo_set_num_threads.restype = None
         for f in (_lib.fqo_table_windowed, _lib.fqo_table_endo, _lib.fqo_mul_batch, _lib.fqo_dh_batch, _lib.fqo_decompose_batch):
             f.restype = None
     return _lib
@@ -83,3 +85,9 @@ def decompose(scalars):
 
 def num_threads():
     return int(lib().fqo_num_threads())
+
+
+def set_num_threads(n):
+    """OpenMP threads of the batch entry points (OMP_NUM_THREADS is only read when libgomp loads)."""
+    lib().fqo_set_num_threads(int(n))
+    return num_threads()

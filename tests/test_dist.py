@@ -67,3 +67,37 @@ def test_two_rank_shard_and_gather_gloo(tmp_path, n):
     mp.spawn(_worker, args=(2, port, n, out), nprocs=2, join=True)
     want = oc.mul(oc.ENDO, seeded_scalars(7, n), None, oc.table(oc.ENDO, _g1()))
     assert np.array_equal(np.load(out), want)
+
+
+def test_bench_gpus_n_launches_its_own_ranks_before_touching_a_gpu(monkeypatch):
+    """`python bench.py --gpus N` from a bare shell: the parent builds a torch.distributed.run command on 127.0.0.1 with
+    a free port, relays the children's return code and never initialises the GPU runtime itself."""
+    import types
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--workload", "cfg4"])
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "2", "--steps", "3", "--workload", "cfg4"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()
+    # under a launcher (RANK set) the same command line is a rank, not a launcher: it must not spawn again
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "3")
+    seen.clear()
+    with pytest.raises(SystemExit, match="WORLD_SIZE=3"):
+        bench.main()
+    assert not seen

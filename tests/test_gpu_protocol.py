@@ -1,0 +1,226 @@
+"""GPU parity of the protocol-level entry points and of the host-array pipeline:
+
+  * fourq_dh_*_bytes_batch  -- decode -> DH -> encode on the device (draft-ladd-cfrg-4q.md:707-723;
+    curve4q.py:49-96, :446-462, :41-46) against o.encode(*o.DH_endo(m, o.decode(B))), with every decode status of
+    tests/golden/wire.json and the DH rejections of tests/golden/dh.json inside the batch;
+  * fourq_dh_exchange_batch -- both halves chained on the device (curve4q.py:731);
+  * the chunked H2D / kernel / D2H pipeline behind every host-array call: pageable and pinned callers, ragged
+    multi-chunk batches, every route, compared with the C oracle;
+  * GFp.select / GFp2.select on the device and DH_core with a caller-supplied `mul`.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import curve4q_oracle as o
+import oracle_c as oc
+from conftest import unhex
+from fourq_amd import _lib, codec
+
+pytestmark = pytest.mark.gpu
+
+G = (o.Gx, o.Gy)
+G1 = o.AffineToR1(o.Gx, o.Gy)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from fourq_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def seeded_scalars(seed, n):
+    rng = random.Random(seed)
+    return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+
+
+def oracle_dh_bytes(m, B, kind="endo", table=None):
+    """(32 bytes, status) the way the reference's three steps compose; status as fourq_dh_*_bytes_batch reports it."""
+    try:
+        P = o.decode(bytes(B))
+    except AttributeError:
+        return bytes(32), _lib.BYTES_DECODE_BASE + _lib.DECODE_REF_ATTRIBUTE_ERROR
+    except Exception as exc:
+        code = _lib.DECODE_RESERVED_BIT if "reserved" in str(exc) else _lib.DECODE_NOT_ON_CURVE
+        return bytes(32), _lib.BYTES_DECODE_BASE + code
+    try:
+        Q = (o.DH_endo if kind == "endo" else o.DH_windowed)(m, P, table=table)
+    except Exception as exc:
+        return bytes(32), (_lib.DH_NOT_ON_CURVE if "not on curve" in str(exc) else _lib.DH_NEUTRAL)
+    return bytes(o.encode(*Q)), 0
+
+
+@pytest.mark.parametrize("kind", ["endo", "windowed"])
+def test_dh_bytes_golden_statuses(eng, golden, kind):
+    w = golden("wire.json", raw=True)
+    dh = golden("dh.json", raw=True)
+    keys = [bytes.fromhex(r[1]) for r in w["roundtrip"][:24]]                      # valid public keys
+    by_kind = {}
+    for r in w["strings"]:                                                         # every decode verdict, a few each
+        by_kind.setdefault(r[1] if r[1] == "ok" else r[2], []).append(bytes.fromhex(r[0]))
+    assert len(by_kind) == 4
+    for rows in by_kind.values():
+        keys += rows[:6]
+    small = [unhex(r[1]) for r in dh["reject"] if "neutral" in r[2] and unhex(r[1]) != G and o.PointOnCurve(unhex(r[1]))]
+    keys += [bytes(o.encode(*P)) for P in small]                                   # on the curve, killed by the cofactor
+    rng = random.Random(4242 + len(kind))
+    ms = [rng.getrandbits(256) for _ in keys]
+    ms[0], ms[1] = 0, o.N                                                          # neutral results from valid keys
+    out, st = eng.dh_bytes(codec.pack_scalars(ms), np.frombuffer(b"".join(keys), dtype=np.uint8).reshape(-1, 32), kind=kind)
+    want = [oracle_dh_bytes(m, B, kind) for m, B in zip(ms, keys)]
+    assert [int(s) for s in st] == [s for _, s in want]
+    assert [bytes(r) for r in out] == [b for b, _ in want]
+    seen = set(int(s) for s in st)
+    assert {0, _lib.DH_NEUTRAL, 16 + 1, 16 + 2, 16 + 3} <= seen
+
+
+def test_dh_bytes_with_table_and_reference_shape(eng, golden):
+    """table given: the reference still tests the decoded point but multiplies through the table (curve4q.py:209, :426)."""
+    g392 = o.MUL_endo(392, G1)
+    T = o.table_endo(g392)
+    w = golden("wire.json", raw=True)
+    keys = [bytes.fromhex(r[1]) for r in w["roundtrip"][:6]] + [bytes.fromhex(w["strings"][0][0])]
+    ms = [random.Random(99).getrandbits(256) for _ in keys]
+    out, st = eng.dh_bytes(codec.pack_scalars(ms), np.frombuffer(b"".join(keys), dtype=np.uint8).reshape(-1, 32), table=codec.pack_table(T))
+    want = [oracle_dh_bytes(m, B, "endo", T) for m, B in zip(ms, keys)]
+    assert [bytes(r) for r in out] == [b for b, _ in want] and [int(s) for s in st] == [s for _, s in want]
+
+
+def test_dh_bytes_large_batch_both_parties(eng):
+    """2^18 + 5 exchanges over the wire (split route, deferred normalisation, three pipeline chunks): both parties agree,
+    a slice agrees with the oracle."""
+    n = (1 << 18) + 5
+    a, b = seeded_scalars(811, n), seeded_scalars(812, n)
+    genc = np.repeat(eng.encode(codec.pack_point(G).reshape(1, 8)), n, axis=0)
+    pa, s1 = eng.dh_bytes(a, genc)
+    pb, s2 = eng.dh_bytes(b, genc)
+    kab, s3 = eng.dh_bytes(a, pb)
+    kba, s4 = eng.dh_bytes(b, pa)
+    assert not (s1.any() or s2.any() or s3.any() or s4.any())
+    assert np.array_equal(kab, kba)
+    for i in (0, 1, n // 2, n - 1):
+        m, bm = codec.unpack_scalars(a[i:i + 1])[0], codec.unpack_scalars(b[i:i + 1])[0]
+        assert bytes(kab[i]) == bytes(o.encode(*o.DH_endo(m, o.DH_endo(bm, G))))
+    # the same through device pointers, nothing but 32-byte strings crossing the ABI
+    import torch
+    dev = torch.device("cuda", 0)
+    to_dev = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x).view(dt)).to(dev)
+    out_d = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    st_d = torch.empty(n, dtype=torch.uint8, device=dev)
+    eng.dh_bytes_dev(to_dev(a, np.int64), to_dev(pb, np.uint8), None, out_d, st_d, n)
+    eng.sync()
+    assert np.array_equal(out_d.cpu().numpy(), kab) and not bool(st_d.any())
+
+
+def test_dh_exchange_on_device(eng, golden):
+    raw = golden("dh.json", raw=True)
+    for a, b, ab in unhex(raw["exchange"]):
+        out, st = eng.dh_exchange(codec.pack_scalars([a]), codec.pack_scalars([b]), codec.pack_point(G))
+        assert st[0] == 0 and codec.unpack_fp2s(out[0]) == ab
+    n = 3000
+    a, b = seeded_scalars(31, n), seeded_scalars(32, n)
+    a[5] = 0                                  # second half ends in the neutral point
+    b[9] = codec.pack_scalars([o.N])[0]       # first half does: its (zeroed) public key is then rejected as "not on curve"
+    t392 = oc.table(oc.ENDO, codec.pack_point(o.MUL_endo(392, G1)))
+    for table in (None, t392):
+        out, st = eng.dh_exchange(a, b, codec.pack_point(G), table392=table)
+        g = np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0)
+        mid, s1 = oc.dh(oc.ENDO, b, g)
+        want, s2 = oc.dh(oc.ENDO, a, mid)
+        ws = np.where(s1 != 0, s1, s2)
+        want[ws != 0] = 0
+        assert np.array_equal(st, ws) and np.array_equal(out, want)
+        assert st[5] == _lib.DH_NEUTRAL and st[9] == _lib.DH_NEUTRAL and not st[:5].any()
+    bad = codec.pack_point(((1, 2), (3, 4)))  # base not on the curve: every exchange is rejected at the first step
+    out, st = eng.dh_exchange(a[:8], b[:8], bad)
+    assert (st == _lib.DH_NOT_ON_CURVE).all() and not out.any()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pipeline_chunks_and_pinned_memory(eng, pinned):
+    """Ragged batches spanning several pipeline chunks, from pageable and from pinned arrays: every host-array entry
+    point agrees with the C oracle (variable base) or with the single-chunk device path."""
+    lanes = eng.lanes
+    n = 2 * lanes + 1234
+    put = (lambda x: eng.host_array(x)) if pinned else (lambda x: x)
+    s = put(seeded_scalars(71, n))
+    te = oc.table(oc.ENDO, codec.pack_point(G1))
+    pts = put(eng.mul_endo_fixed(seeded_scalars(72, n), te))
+    out_buf = eng.host_empty((n, 20)) if pinned else None
+    got = eng.mul_endo(s, pts, out=out_buf)
+    st = eng.host_stats()
+    assert st["chunks"] == 3 and st["pinned_in"] == int(pinned) and st["pinned_out"] == int(pinned)
+    assert st["h2d_bytes"] == n * 192 and st["d2h_bytes"] == n * 160 and st["h2d_ms"] > 0 and st["d2h_ms"] > 0
+    assert np.array_equal(got, oc.mul(oc.ENDO, np.asarray(s), np.asarray(pts)))
+    m = lanes + 77                                             # windowed: two chunks of the fused route
+    assert np.array_equal(eng.mul_windowed(s[:m], pts[:m]), oc.mul(oc.WINDOWED, np.asarray(s[:m]), np.asarray(pts[:m])))
+    tw = oc.table(oc.WINDOWED, codec.pack_point(G1))
+    n4 = 4 * lanes + 9                                         # fixed base: chunks of 4 x lanes
+    s4 = put(seeded_scalars(73, n4))
+    got = eng.mul_windowed_fixed(s4, tw)
+    assert eng.host_stats()["chunks"] == 2
+    assert np.array_equal(got, oc.mul(oc.WINDOWED, np.asarray(s4), None, tw))
+    g = np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0)
+    aff, st0 = oc.dh(oc.ENDO, seeded_scalars(72, n), g)        # affine inputs: DH_endo(k_i, G)
+    assert not st0.any()
+    aff = put(aff)
+    out, st = eng.dh_endo(s, aff)                              # n >= 2 x lanes: split route, chunk = 4 x lanes -> one chunk
+    want, ws = oc.dh(oc.ENDO, np.asarray(s), np.asarray(aff))
+    assert np.array_equal(out, want) and np.array_equal(st, ws)
+    flags = put((np.frombuffer(random.Random(74).getrandbits(8 * n4).to_bytes(n4, "little"), dtype=np.uint8) & 1).copy())
+    p4 = put(eng.mul_endo_fixed(seeded_scalars(75, n4), te))
+    got = eng.mul_endo_mixed(s4, p4, flags, te)
+    want = np.where(np.asarray(flags).reshape(-1, 1) != 0, oc.mul(oc.ENDO, np.asarray(s4), np.asarray(p4)), oc.mul(oc.ENDO, np.asarray(s4), None, te))
+    assert np.array_equal(got, want)
+    for arr in (s, pts, s4, aff, flags, p4) + ((out_buf,) if pinned else ()):
+        if pinned:
+            eng.host_free(arr)
+
+
+def test_set_stream_restages_the_fixed_base_table(eng):
+    import torch
+    tw = oc.table(oc.WINDOWED, codec.pack_point(G1))
+    te = oc.table(oc.ENDO, codec.pack_point(G1))
+    n = 5000
+    s = seeded_scalars(81, n)
+    want_w = oc.mul(oc.WINDOWED, s, None, tw)
+    want_e = oc.mul(oc.ENDO, s, None, te)
+    dev = torch.device("cuda", 0)
+    s_d = torch.from_numpy(s.view(np.int64)).to(dev)
+    out = torch.empty((n, 20), dtype=torch.int64, device=dev)
+    other = torch.cuda.Stream(device=dev)
+    for stream, table, want in ((None, tw, want_w), (other, tw, want_w), (None, te, want_e), (other, te, want_e), (other, tw, want_w)):
+        eng.set_stream(stream.cuda_stream if stream is not None else None)
+        eng.mul_windowed_fixed_dev(s_d, table, out, n) if table is tw else eng.mul_endo_fixed_dev(s_d, table, out, n)
+        eng.sync()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    eng.set_stream(None)
+
+
+def test_select_and_dh_core_with_any_callable(golden):
+    from fourq_amd import curve4q as c
+    rng = random.Random(5)
+    for _ in range(16):
+        x, y = rng.getrandbits(127), rng.getrandbits(127)
+        a, b = (rng.getrandbits(127), rng.getrandbits(127)), (rng.getrandbits(127), rng.getrandbits(127))
+        for bit in (0, 1):
+            assert c.GFp.select(bit, x, y) == o.fp_select(bit, x, y) == (x if bit else y)
+            assert c.GFp2.select(bit, a, b) == o.f2_select(bit, a, b) == (a if bit else b)
+    assert c.GFp.select(1, (1 << 128) - 1, 0) == (1 << 128) - 1            # raw bits, not reduced (as the reference)
+    raw = golden("dh.json", raw=True)
+    calls = []
+
+    def my_mul(m, Q, table=None):              # a caller's own multiplication routine, as DH_core allows (curve4q.py:446)
+        calls.append(m)
+        return c.MUL_windowed(m, Q, table=table)
+
+    for m, Pt, e, w in unhex(raw["dh"])[:3]:
+        assert c.DH_core(m, Pt, my_mul) == w == o.DH_core(m, Pt, o.MUL_windowed)
+    assert len(calls) == 3
+    for m, Pt, msg in raw["reject"][:2]:
+        with pytest.raises(Exception) as ei:
+            c.DH_core(int(m, 16), unhex(Pt), my_mul)
+        assert str(ei.value) == msg
