@@ -516,7 +516,8 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": rec["workload"], "batch_per_gpu": n, "parallelism": "independent shards x%d, no data-path collective" % world,
-                       "clock_settle_ms": b.settle_ms, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                       "clock_settle_ms": b.settle_ms, "table_selection": "constant-time (every entry read, FOURQ_CT_SELECT=1)" if b.eng.ct_select
+                       else "by address, as the reference (default; not constant-time)", "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if world > 1 else None},
             "roofline": rec["roofline"], "valu_roofline": rec["valu_roofline"], "parity": parity,
         }

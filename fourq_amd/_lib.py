@@ -33,6 +33,8 @@ PROTOTYPES = {
     "fourq_ctx_destroy": (c_int, [c_void_p]),
     "fourq_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "fourq_ctx_sync": (c_int, [c_void_p]),
+    "fourq_ctx_set_ct_select": (c_int, [c_void_p, c_int]),
+    "fourq_ctx_get_ct_select": (c_int, [c_void_p, POINTER(c_int)]),
     "fourq_ctx_lanes": (c_int, [c_void_p, POINTER(c_size_t)]),
     "fourq_host_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "fourq_host_free": (c_int, [c_void_p, c_void_p]),

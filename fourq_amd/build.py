@@ -13,7 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
-SOURCES = ["fourq_amd.hip", "fourq_chain.hip"]      # two translation units: FQ_CHAIN=0 / 1 (kernels.hip.h)
+# four translation units: FQ_CHAIN=0 / 1 (kernels.hip.h), and the constant-time-selection builds of both flavours
+SOURCES = ["fourq_amd.hip", "fourq_chain.hip", "fourq_ct_fused.hip", "fourq_ct_chain.hip"]
 HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 

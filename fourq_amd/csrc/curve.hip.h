@@ -451,6 +451,150 @@ template <typename P> FQ_DEV R1 affine_table_start(const P* entry, u32 neg_mask)
     return r;
 }
 
+// ---- constant-time selection (FOURQ_CT_SELECT; draft-ladd-cfrg-4q.md:753-758) --------------------------------
+// "Implementations MUST ensure that ... memory addresses accessed do not depend on secret data."  The default ladders
+// above use the digit as an address, exactly as the reference does (curve4q.py:232, :440: T[ind[i]]), and the sign
+// as an address choice.  The sources below read EVERY entry of the table at every step and keep the wanted one with
+// masks derived arithmetically from the digit (one v_and_or_b32 per limb and entry); the N/D swap of a negated entry
+// is a masked XOR swap, -F a masked negation.  Same values, hence the same R1 tuples.
+//   ScanMem   the table in LDS (all lanes read the same addresses: broadcasts) or in global memory
+//   ScanRegs  a per-lane table held in registers (fused variable-base kernels: no memory traffic in the ladder)
+FQ_DEV u32 eq_mask(u32 a, u32 b) { return 0u - (u32)(a == b); }
+template <int N> FQ_DEV void masked_or(u32 acc[N], const u32 v[N], u32 m) {
+#pragma unroll
+    for (int i = 0; i < N; i++) acc[i] |= v[i] & m;
+}
+FQ_DEV Fe2<1> fe2_from_limbs(const u32 w[10]) {
+    Fe2<1> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { r.re.l[i] = w[i]; r.im.l[i] = w[5 + i]; }
+    return r;
+}
+// masked swap: (a, b) -> (b, a) where mask == ~0
+FQ_DEV void fe2_cswap(Fe2<1>& a, Fe2<1>& b, u32 mask) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        u32 t = (a.re.l[i] ^ b.re.l[i]) & mask; a.re.l[i] ^= t; b.re.l[i] ^= t;
+        u32 u = (a.im.l[i] ^ b.im.l[i]) & mask; a.im.l[i] ^= u; b.im.l[i] ^= u;
+    }
+}
+template <int ENTRIES, typename TP> struct ScanMem {
+    const TP* tbl;
+    int stride;                                    // dwords between entries; coordinates are COORD_U32 apart
+    // Two entries per round, rounds fenced: left alone the scheduler hoists all 3 * ENTRIES loads ahead of the masking
+    // and the 128-VGPR kernels spill (measured: 1.3 KB of scratch per lane).
+    FQ_DEV Fe2<1> coord(u32 digit, int c) const {  // coordinate c of entry `digit`
+        static_assert(ENTRIES % 2 == 0, "entries are scanned in pairs");
+        u32 acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < ENTRIES; k += 2) {
+            const uint4* q0 = reinterpret_cast<const uint4*>(tbl + k * stride + c * COORD_U32);
+            const uint4* q1 = reinterpret_cast<const uint4*>(tbl + (k + 1) * stride + c * COORD_U32);
+            const uint4 a0 = q0[0], b0 = q0[1], d0 = q0[2], a1 = q1[0], b1 = q1[1], d1 = q1[2];
+            const u32 v0[10] = { a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x, d0.y };
+            const u32 v1[10] = { a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w, d1.x, d1.y };
+            masked_or<10>(acc, v0, eq_mask(digit, (u32)k));
+            masked_or<10>(acc, v1, eq_mask(digit, (u32)k + 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return fe2_from_limbs(acc);
+    }
+};
+template <int ENTRIES, int COORDS> struct ScanRegs {
+    u32 w[ENTRIES][COORDS * 10];
+    template <typename TP> FQ_DEV void load(const TP* tbl, int stride) {
+#pragma unroll
+        for (int k = 0; k < ENTRIES; k++) {
+#pragma unroll
+            for (int c = 0; c < COORDS; c++) {
+                const uint4* q = reinterpret_cast<const uint4*>(tbl + k * stride + c * COORD_U32);
+                const uint4 a = q[0], b = q[1], d = q[2];
+                const u32 v[10] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y };
+#pragma unroll
+                for (int i = 0; i < 10; i++) w[k][c * 10 + i] = v[i];
+            }
+        }
+    }
+    FQ_DEV Fe2<1> coord(u32 digit, int c) const {
+        u32 acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < ENTRIES; k++) masked_or<10>(acc, &w[k][c * 10], eq_mask(digit, (u32)k));
+        return fe2_from_limbs(acc);
+    }
+};
+// Q + (+-T[digit]), every entry read: the constant-time form of add_table
+template <int CH, typename SRC> FQ_DEV R1 add_scan(const R1& q, const SRC& src, u32 digit, u32 neg_mask) {
+    Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
+    Fe2<2> N1 = fe2_add(q.X, q.Y);
+    Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
+    Fe2<1> tN = src.coord(digit, 0), tD = src.coord(digit, 1);
+    fe2_cswap(tN, tD, neg_mask);                                   // R2neg: (D, N, E, -F)
+    Fe2<1> A = fe2_mulx<CH>(D1, tD);
+    Fe2<1> B = fe2_mulx<CH>(N1, tN);
+    Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(src.coord(digit, 3), neg_mask), T);
+    Fe2<1> D = fe2_mulx<CH>(src.coord(digit, 2), q.Z);
+    Fe2<3> E = fe2_subx<CH>(B, A);
+    Fe2<3> F = fe2_subx<CH>(D, C);
+    Fe2<2> G = fe2_add(D, C);
+    Fe2<2> H = fe2_add(B, A);
+    R1 r;
+    r.X = fe2_mulx<CH>(E, F);
+    r.Z = fe2_mulx<CH>(G, F);
+    r.Y = fe2_mulx<CH>(G, H);
+    r.Ta = widen<4>(E);
+    r.Tb = H;
+    return r;
+}
+template <typename SRC> FQ_DEV Proj<1, 1, 1> start_scan(const SRC& src, u32 digit, u32 neg_mask) {
+    Fe2<1> N = src.coord(digit, 0), D = src.coord(digit, 1);
+    fe2_cswap(N, D, neg_mask);
+    Proj<1, 1, 1> r;
+    r.X = fe2_carry(fe2_sub(N, D));
+    r.Y = fe2_carry(fe2_add(D, N));
+    r.Z = src.coord(digit, 2);
+    return r;
+}
+// the comb's mixed addition and starting point with every one of the block's entries read (3 coordinates each)
+template <int CH, typename SRC> FQ_DEV R1 add_affine_scan(const R1& q, const SRC& src, u32 idx, u32 neg_mask) {
+    Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
+    Fe2<2> N1 = fe2_add(q.X, q.Y);
+    Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
+    Fe2<1> tN = src.coord(idx, 0), tD = src.coord(idx, 1);
+    fe2_cswap(tN, tD, neg_mask);
+    Fe2<1> A = fe2_mulx<CH>(D1, tD);
+    Fe2<1> B = fe2_mulx<CH>(N1, tN);
+    Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(src.coord(idx, 2), neg_mask), T);
+    Fe2<2> D = fe2_dbl(q.Z);
+    Fe2<3> E = fe2_subx<CH>(B, A);
+    Fe2<3> G = fe2_add(D, C);
+    Fe2<2> H = fe2_add(B, A);
+    R1 r;
+    if constexpr (CH == 2) {
+        Fe2<3> F = fe2_sub_signed(D, C);
+        r.X = fe2_mulx<CH>(E, F);
+        r.Z = fe2_mulx<CH>(G, F);
+    } else {
+        Fe2<4> F = fe2_sub(D, C);
+        r.X = fe2_mulx<CH>(E, F);
+        r.Z = fe2_mulx<CH>(G, F);
+    }
+    r.Y = fe2_mulx<CH>(G, H);
+    r.Ta = widen<4>(E);
+    r.Tb = H;
+    return r;
+}
+template <typename SRC> FQ_DEV R1 affine_scan_start(const SRC& src, u32 idx, u32 neg_mask) {
+    Fe2<1> N = src.coord(idx, 0), D = src.coord(idx, 1);
+    fe2_cswap(N, D, neg_mask);
+    R1 r;
+    r.X = fe2_carry(fe2_sub(N, D));
+    r.Y = fe2_carry(fe2_add(N, D));
+    r.Z = fe2_carry(fe2_dbl(fe2_one()));
+    r.Ta = widen<4>(r.X);
+    r.Tb = widen<2>(fe2_mul(r.Y, fe2_half_const()));
+    return r;
+}
+
 // R2toR4(selectpt(s, T, nT)): the ladder's starting point (curve4q.py:229, :437)
 template <typename P> FQ_DEV Proj<1, 1, 1> start_table(const P* entry, u32 neg_mask) {
     const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;

@@ -51,8 +51,11 @@ __global__ void table_build_kernel(int algo, const u64* p_r1, u32* scratch, u64*
 // or ~0 for a fixed-base element (shared table).  Sixteen flags per lane, a block scan in LDS and one atomic per
 // 4 096 elements; one atomic per element (or per wave) serialises on the counter.
 constexpr int PART_PER_LANE = 16;
-__global__ __launch_bounds__(BLOCK) void partition_kernel(const uint8_t* flags, u32 n, u32 first_id, u32* var_list, u32* slot_of, u32* counter) {
-    __shared__ u32 scan[BLOCK], base;
+// fix_list (optional; constant-time mode runs the two kinds as two launches): the ids of the fixed-base elements,
+// counted in counter[1].
+__global__ __launch_bounds__(BLOCK) void partition_kernel(const uint8_t* flags, u32 n, u32 first_id, u32* var_list, u32* slot_of, u32* counter,
+                                                          u32* fix_list) {
+    __shared__ u32 scan[BLOCK], base, base_fix;
     const u32 t = threadIdx.x;
     const u32 first = (blockIdx.x * BLOCK + t) * PART_PER_LANE;
     const u32 valid = first < n ? (n - first < (u32)PART_PER_LANE ? n - first : (u32)PART_PER_LANE) : 0u;
@@ -77,14 +80,26 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const uint8_t* flags, 
         scan[t] += below;
         __syncthreads();
     }
-    if (t == BLOCK - 1) base = atomicAdd(counter, scan[t]);
+    if (t == BLOCK - 1) {
+        base = atomicAdd(counter, scan[t]);
+        if (fix_list) {                                   // fixed-base elements of this block = its valid elements - variable ones
+            const u32 block_first = blockIdx.x * BLOCK * PART_PER_LANE;
+            const u32 block_valid = block_first < n ? (n - block_first < (u32)(BLOCK * PART_PER_LANE) ? n - block_first : (u32)(BLOCK * PART_PER_LANE)) : 0u;
+            base_fix = atomicAdd(counter + 1, block_valid - scan[t]);
+        }
+    }
     __syncthreads();
     u32 rank = base + scan[t] - mine;
+    // fixed-base elements before this lane inside the block: elements before it minus variable ones before it
+    u32 rank_fix = fix_list ? base_fix + (t * PART_PER_LANE - (scan[t] - mine)) : 0u;
 #pragma unroll
     for (int k = 0; k < PART_PER_LANE; k++) {
         if ((u32)k >= valid) break;
         if (f[k] != 0) { var_list[rank] = first_id + first + k; slot_of[first + k] = rank++; }
-        else slot_of[first + k] = ~0u;
+        else {
+            slot_of[first + k] = ~0u;
+            if (fix_list) fix_list[rank_fix++] = first_id + first + k;
+        }
     }
 }
 
@@ -317,6 +332,8 @@ struct fourq_ctx {
     u32* part_counter = nullptr;   // mixed batches: number of variable-base elements of the current round (device side)
     u32* part_list = nullptr;      // their ids, split_chunk entries
     u32* part_slot = nullptr;      // per element of the round: scratch slot of its table, ~0 = shared table
+    u32* part_fix = nullptr;       // constant-time mode: ids of the round's fixed-base elements
+    bool ct = false;               // constant-time table selection (FOURQ_CT_SELECT / fourq_ctx_set_ct_select)
     uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
     size_t proj_capacity = 0;
     int norm_k = -1;               // FOURQ_NORM_K: 0 = always invert per element, 2/4/8 = always batch; -1 = by batch size
@@ -332,6 +349,7 @@ struct fourq_ctx {
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
     fourq_host_stats host_stats = {};
+    bool host_bounce = true;       // FOURQ_HOST_BOUNCE=0: hand pageable arrays to hipMemcpyAsync directly (measurement knob)
     char err[256] = { 0 };
 };
 
@@ -370,7 +388,10 @@ template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs
     unsigned grid = (unsigned)(blocks_needed < blocks_max ? blocks_needed : blocks_max);
     a.scratch = c->scratch;
     a.table = c->table_limbs;
-    if (SRC == FUSED) {                     // this translation unit's code object (FQ_CHAIN=0)
+    if (c->ct) {                            // constant-time selection: fourq_ct_fused.hip / fourq_ct_chain.hip
+        if (SRC == PREBUILT) return FOURQ_ERR_INVALID;    // the two-kernel route is not taken in this mode
+        HIPRC_TRY(c, SRC == FUSED ? ct_launch_fused(ALGO, DH, grid, c->stream, a) : ct_launch_lds(ALGO, DH, grid, c->stream, a));
+    } else if (SRC == FUSED) {              // this translation unit's code object (FQ_CHAIN=0)
         hipLaunchKernelGGL((ladder_kernel<ALGO, FUSED, DH>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
         HIP_TRY(c, hipGetLastError());
     } else {                                // fourq_chain.hip's (FQ_CHAIN=1)
@@ -382,6 +403,7 @@ template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs
 // plain MUL_endo, whose 64-step ladder hardly amortises the second launch and the colder table gathers (4 waves
 // per SIMD put 486 MB of tables in flight, past the Infinity Cache); plain MUL_endo therefore stays fused.
 bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
+    if (c->ct) return false;        // constant-time mode keeps the lane's table in registers: fused kernels only
     return (algo == WINDOWED || dh || c->split_all) && n >= c->split_min;
 }
 template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
@@ -528,8 +550,9 @@ int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* o
     if (chunk > n) chunk = n;
     size_t off_in[PIPE_MAX_ARRAYS], off_out[PIPE_MAX_ARRAYS], slot = 0;
     bool pin_in[PIPE_MAX_ARRAYS], pin_out[PIPE_MAX_ARRAYS], bounce = false;
-    for (int i = 0; i < n_in; i++) { off_in[i] = slot; slot += align256(chunk * in[i].stride); pin_in[i] = is_pinned(in[i].src); bounce |= !pin_in[i]; }
-    for (int i = 0; i < n_out; i++) { off_out[i] = slot; slot += align256(chunk * out[i].stride); pin_out[i] = is_pinned(out[i].dst); bounce |= !pin_out[i]; }
+    // "pinned" below = "copy by DMA straight from / to the caller's array"
+    for (int i = 0; i < n_in; i++) { off_in[i] = slot; slot += align256(chunk * in[i].stride); pin_in[i] = !c->host_bounce || is_pinned(in[i].src); bounce |= !pin_in[i]; }
+    for (int i = 0; i < n_out; i++) { off_out[i] = slot; slot += align256(chunk * out[i].stride); pin_out[i] = !c->host_bounce || is_pinned(out[i].dst); bounce |= !pin_out[i]; }
     const size_t chunks = (n + chunk - 1) / chunk;
     const int slots = chunks < (size_t)PIPE_SLOTS ? (int)chunks : PIPE_SLOTS;
     int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
@@ -696,6 +719,8 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         c->split_min = 2 * c->lanes;                       // below two full waves of fused work the second launch does not pay
         if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
+        if (const char* env = getenv("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
+        if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
         c->split_chunk = c->lanes_w4;
         if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }
@@ -703,7 +728,8 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (hipMalloc(&c->scratch, slots * SLOT_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
-        if (hipMalloc(&c->part_counter, sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->part_counter, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->part_fix, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_list, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_slot, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->comb_limbs, COMB_POINTS * COMB_ENTRY_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
@@ -725,6 +751,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->part_counter) (void)hipFree(c->part_counter);
     if (c->part_list) (void)hipFree(c->part_list);
     if (c->part_slot) (void)hipFree(c->part_slot);
+    if (c->part_fix) (void)hipFree(c->part_fix);
     if (c->comb_limbs) (void)hipFree(c->comb_limbs);
     if (c->comb_packed) (void)hipFree(c->comb_packed);
     if (c->stage) (void)hipFree(c->stage);
@@ -754,6 +781,16 @@ FQ_API int fourq_ctx_set_stream(fourq_ctx* c, void* hip_stream) {
         c->comb_staged = false;
     }
     c->stream = next;
+    return FOURQ_OK;
+}
+FQ_API int fourq_ctx_set_ct_select(fourq_ctx* c, int on) {
+    if (!c) return FOURQ_ERR_INVALID;
+    c->ct = on != 0;
+    return FOURQ_OK;
+}
+FQ_API int fourq_ctx_get_ct_select(const fourq_ctx* c, int* on) {
+    if (!c || !on) return FOURQ_ERR_INVALID;
+    *on = c->ct ? 1 : 0;
     return FOURQ_OK;
 }
 FQ_API int fourq_ctx_sync(fourq_ctx* c) {
@@ -838,13 +875,24 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     const size_t per_block = (size_t)BLOCK * PART_PER_LANE;
     for (size_t off = 0; off < n; off += c->split_chunk) {
         const u32 m = (u32)(n - off < c->split_chunk ? n - off : c->split_chunk);
-        HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, sizeof(u32), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, 2 * sizeof(u32), c->stream));
         hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((m + per_block - 1) / per_block)), dim3(BLOCK), 0, c->stream,
-                           flags + off, m, (u32)off, c->part_list, c->part_slot, c->part_counter);
+                           flags + off, m, (u32)off, c->part_list, c->part_slot, c->part_counter, c->ct ? c->part_fix : nullptr);
         HIP_TRY(c, hipGetLastError());
         LadderArgs a = {};
         a.scalars = s; a.points = p; a.out = o; a.n = m;
         a.scratch = c->scratch; a.table = c->table_limbs;
+        if (c->ct) {
+            // constant-time selection: which elements are fixed-base is public, the digits are not.  The variable-base
+            // ids go through the fused kernel (table in registers), the fixed-base ids through the LDS kernel; both
+            // read their element counts on the device.
+            LadderArgs av = a, af = a;
+            av.index = c->part_list; av.n_dev = c->part_counter;
+            af.index = c->part_fix; af.n_dev = c->part_counter + 1;
+            if ((rc = launch_ladder<ENDO, FUSED, false>(c, av))) return rc;
+            if ((rc = launch_ladder<ENDO, LDS, false>(c, af))) return rc;
+            continue;
+        }
         LadderArgs ap = a;
         ap.index = c->part_list; ap.n_dev = c->part_counter;
         HIPRC_TRY(c, chain_launch_prep(ENDO, false, (m + BLOCK - 1) / BLOCK, c->stream, ap));
@@ -908,8 +956,8 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
     if (rc) return rc;
     size_t blocks = (n + BLOCK - 1) / BLOCK, blocks_max = c->lanes_w4 / BLOCK;
-    HIPRC_TRY(c, chain_launch_comb((unsigned)(blocks < blocks_max ? blocks : blocks_max), c->stream, scalars, c->comb_limbs, out, status,
-                                   group ? c->proj : nullptr, (u32)c->proj_capacity, (u32)n));
+    HIPRC_TRY(c, (c->ct ? ct_launch_comb : chain_launch_comb)((unsigned)(blocks < blocks_max ? blocks : blocks_max), c->stream, scalars, c->comb_limbs, out, status,
+                                                             group ? c->proj : nullptr, (u32)c->proj_capacity, (u32)n));
     if (group) HIPRC_TRY(c, chain_launch_normalize(group, c->stream, c->proj, (u32)c->proj_capacity, out, status, (u32)n));
     return FOURQ_OK;
 }

@@ -1,0 +1,29 @@
+// Fourth translation unit of libfourq_amd.so: the fixed-base (LDS) ladders and the comb with CONSTANT-TIME table
+// selection (FOURQ_CT_SELECT / fourq_ctx_set_ct_select).  Same build flavour as fourq_chain.hip (FQ_CHAIN=1): every
+// entry of the shared table is read by every lane at every step (same addresses across the wave: LDS broadcasts).
+#ifndef FQ_CHAIN
+#define FQ_CHAIN 1
+#endif
+#include "kernels.hip.h"
+
+namespace fq {
+
+namespace {
+template <int ALGO> int launch_lds(bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    if (!dh) hipLaunchKernelGGL((ladder_kernel<ALGO, LDS, false, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else if (a.proj) hipLaunchKernelGGL((ladder_kernel<ALGO, LDS, true, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((ladder_kernel<ALGO, LDS, true, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+int ct_launch_lds(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    return algo == ENDO ? launch_lds<ENDO>(dh, grid, stream, a) : launch_lds<WINDOWED>(dh, grid, stream, a);
+}
+int ct_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
+    if (proj) hipLaunchKernelGGL((comb_kernel<true, true>), dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
+    else hipLaunchKernelGGL((comb_kernel<false, true>), dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
+    return (int)hipGetLastError();
+}
+
+}  // namespace fq

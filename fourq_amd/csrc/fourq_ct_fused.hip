@@ -1,0 +1,22 @@
+// Third translation unit of libfourq_amd.so: the fused variable-base kernels with CONSTANT-TIME table selection
+// (FOURQ_CT_SELECT / fourq_ctx_set_ct_select; kernels.hip.h, curve.hip.h).  Same build flavour as fourq_amd.hip
+// (FQ_CHAIN=0); the lane's 8-entry table is loaded into registers once and every ladder step scans all of it.
+#ifndef FQ_CHAIN
+#define FQ_CHAIN 0
+#endif
+#include "kernels.hip.h"
+
+namespace fq {
+
+int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    if (algo == ENDO) {
+        if (dh) hipLaunchKernelGGL((ladder_kernel<ENDO, FUSED, true, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((ladder_kernel<ENDO, FUSED, false, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    } else {
+        if (dh) hipLaunchKernelGGL((ladder_kernel<WINDOWED, FUSED, true, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((ladder_kernel<WINDOWED, FUSED, false, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace fq

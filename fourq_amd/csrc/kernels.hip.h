@@ -215,6 +215,32 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename TP> F
     return ladder_result<CH>(Q);
 }
 
+// The ladders with constant-time selection (curve.hip.h, "constant-time selection"): `src` reads the whole table at
+// every step.  Same digits, same DAG, same R1 tuple as the ladders above.
+template <int CH, typename SRC> FQ_DEV R1 ladder_endo_scan(const EndoDigits& e, const SRC& src) {
+    Proj<1, 1, 1> q4 = start_scan(src, e.top & 7, 0u);
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+#pragma unroll 1
+    for (int i = 63; i >= 0; i--) {
+        Q = dbl<CH>(Q.X, Q.Y, Q.Z);
+        Q = add_scan<CH>(Q, src, endo_digit(e, i), endo_neg_mask(e, i));
+    }
+    return ladder_result<CH>(Q);
+}
+template <int CH, typename SRC> FQ_DEV R1 ladder_windowed_scan(const WinScalar& w, const SRC& src) {
+    u32 code = win_top_code(w);
+    Proj<1, 1, 1> q4 = start_scan(src, code & 7, (code >> 3) - 1u);
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+#pragma unroll 1
+    for (int i = 61; i >= 0; i--) {
+        code = win_code_from_window(win_window(w, i));
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
+        Q = add_scan<CH>(Q, src, code & 7, (code >> 3) - 1u);
+    }
+    return ladder_result<CH>(Q);
+}
+
 // The same table for the fused kernels (one wave per SIMD, up to 512 registers per lane).  gfx950 counts loads and
 // stores in one vmcnt, and once both kinds are in flight a wait for a load is a wait for everything, so a lone wave
 // that reads back what it has just stored sits out a store acknowledgement.  Here every memory operation is issued
@@ -304,7 +330,9 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
 
 // ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
 // DEFER (DH only): leave (X, Y, Z) in a.proj for normalize_kernel instead of inverting Z here.
-template <int ALGO, int SRC, bool DH, bool DEFER = false>
+// CT: constant-time table selection (every entry read at every step); FUSED keeps the lane's table in registers,
+// LDS / PREBUILT scan the table where it lies.
+template <int ALGO, int SRC, bool DH, bool DEFER = false, bool CT = false>
 __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
     static_assert(!DEFER || DH, "only DH outputs are normalised");
     __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : 4];
@@ -353,10 +381,24 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             decompose(m, v);
             EndoDigits e = recode(v);
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
+            if constexpr (CT && SRC == FUSED) {
+                ScanRegs<8, 4> regs;
+                regs.load(tbl, R2_LIMBS);
+                Q = ladder_endo_scan<CH>(e, regs);
+            } else if constexpr (CT) {
+                Q = SRC == LDS ? ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 }) : ladder_endo_scan<CH>(e, ScanMem<8, u32>{ tbl, R2_LIMBS });
+            } else
             Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(e, tbl, R2_LIMBS);
         } else {
             WinScalar w = win_reduce(m);
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
+            if constexpr (CT && SRC == FUSED) {
+                ScanRegs<8, 4> regs;
+                regs.load(tbl, R2_LIMBS);
+                Q = ladder_windowed_scan<CH>(w, regs);
+            } else if constexpr (CT) {
+                Q = SRC == LDS ? ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 }) : ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ tbl, R2_LIMBS });
+            } else
             Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(w, tbl, R2_LIMBS);
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
@@ -398,7 +440,7 @@ constexpr int COMB_LDS_U32 = COMB_ENTRY_U32 + 4;              // padded stride i
 #if FQ_CHAIN   // only fourq_chain.hip launches it
 // [m]B, affine, from the comb: 9 doublings + 49 mixed additions per element
 constexpr int COMB_MODE = FQ_SIGNED_LADDER ? 2 : 1;          // the comb's additions run on signed limbs like the LDS ladders
-template <bool DEFER>
+template <bool DEFER, bool CT = false>
 __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
     __shared__ __attribute__((aligned(16))) u32 lds[COMB_POINTS * COMB_LDS_U32];
     for (int i = threadIdx.x; i < COMB_POINTS * COMB_ENTRY_U32; i += BLOCK)
@@ -419,11 +461,18 @@ __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, cons
 #pragma unroll 1
             for (int j = 0; j < COMB_V; j++) {
                 const int col = COMB_E * j + i;
-                const u32* entry = lds + ((j << (COMB_W - 1)) + comb_index(c, col)) * COMB_LDS_U32;
                 const u32 neg = comb_neg_mask(c, col);
-                if (i == COMB_E - 1 && j == 0) { Q = affine_table_start(entry, neg); continue; }
-                if (j == 0) Q = dbl<COMB_MODE>(Q.X, Q.Y, Q.Z);
-                Q = add_affine_table<COMB_MODE>(Q, entry, neg);
+                if constexpr (CT) {                      // all 16 entries of block j are read; the index only forms masks
+                    const ScanMem<1 << (COMB_W - 1), u32> block{ lds + (j << (COMB_W - 1)) * COMB_LDS_U32, COMB_LDS_U32 };
+                    if (i == COMB_E - 1 && j == 0) { Q = affine_scan_start(block, comb_index(c, col), neg); continue; }
+                    if (j == 0) Q = dbl<COMB_MODE>(Q.X, Q.Y, Q.Z);
+                    Q = add_affine_scan<COMB_MODE>(Q, block, comb_index(c, col), neg);
+                } else {
+                    const u32* entry = lds + ((j << (COMB_W - 1)) + comb_index(c, col)) * COMB_LDS_U32;
+                    if (i == COMB_E - 1 && j == 0) { Q = affine_table_start(entry, neg); continue; }
+                    if (j == 0) Q = dbl<COMB_MODE>(Q.X, Q.Y, Q.Z);
+                    Q = add_affine_table<COMB_MODE>(Q, entry, neg);
+                }
             }
         }
         Q = ladder_result<COMB_MODE>(Q);
@@ -516,5 +565,9 @@ int chain_launch_ladder(int algo, int src, bool dh, unsigned grid, hipStream_t s
 int chain_launch_prep(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n);
 int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
+// constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)
+int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_lds(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);        // defers when a.proj != NULL
+int ct_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n);
 
 }  // namespace fq

@@ -75,6 +75,18 @@ class Engine:
     def sync(self):
         self._ck(self._lib.fourq_ctx_sync(self._ctx))
 
+    @property
+    def ct_select(self):
+        """Constant-time table selection (fourq_ctx_set_ct_select): False by default -- the digit is an address, as in
+        the reference; True reads the whole table at every step.  Results are identical."""
+        on = ctypes.c_int()
+        self._ck(self._lib.fourq_ctx_get_ct_select(self._ctx, ctypes.byref(on)))
+        return bool(on.value)
+
+    @ct_select.setter
+    def ct_select(self, on):
+        self._ck(self._lib.fourq_ctx_set_ct_select(self._ctx, 1 if on else 0))
+
     # ---- pinned host memory (the fast path of the host-pointer calls) ---------------------------
     def host_empty(self, shape, dtype=np.uint64):
         """Uninitialised numpy array in pinned host memory (fourq_host_alloc): the host-array entry points move such

@@ -79,6 +79,14 @@ int fourq_ctx_destroy(fourq_ctx *ctx);
  * context's own stream.  The context never synchronises an external stream behind the caller's back. */
 int fourq_ctx_set_stream(fourq_ctx *ctx, void *hip_stream);
 int fourq_ctx_sync(fourq_ctx *ctx);
+/* Constant-time table selection (draft-ladd-cfrg-4q.md:753-758: "memory addresses accessed [must] not depend on secret
+ * data").  OFF by default: the ladders then use a digit of the scalar as a table address, exactly as the reference
+ * does (curve4q.py:232, :440), which is NOT constant-time with respect to the scalar.  ON (this call, or
+ * FOURQ_CT_SELECT=1 in the environment when the context is created): every ladder step reads the whole table and
+ * keeps the wanted entry by masks; per-lane tables live in registers; signs are applied arithmetically.  Results are
+ * bit-identical in both modes; the price of ON is in DESIGN.md section 10. */
+int fourq_ctx_set_ct_select(fourq_ctx *ctx, int on);
+int fourq_ctx_get_ct_select(const fourq_ctx *ctx, int *on);
 /* Resident lanes the ladder kernels are launched with (scratch is sized for this many). */
 int fourq_ctx_lanes(const fourq_ctx *ctx, size_t *lanes);
 

@@ -44,3 +44,15 @@ def golden():
         return cache[key]
 
     return get
+
+
+@pytest.fixture(scope="module", params=[False, True], ids=["select-by-address", "constant-time"])
+def eng(request):
+    """One engine per test module and selection mode: the default ladders (a digit of the scalar is a table address,
+    as in the reference) and FOURQ_CT_SELECT's full-table scans must give bit-identical results on the whole suite."""
+    from fourq_amd import Engine
+    e = Engine(0)
+    e.ct_select = request.param
+    assert e.ct_select == request.param
+    yield e
+    e.close()

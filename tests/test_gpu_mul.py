@@ -15,14 +15,6 @@ pytestmark = pytest.mark.gpu
 G1 = o.AffineToR1(o.Gx, o.Gy)
 
 
-@pytest.fixture(scope="module")
-def eng():
-    from fourq_amd import Engine
-    e = Engine(0)
-    yield e
-    e.close()
-
-
 def seeded_scalars(seed, n):
     rng = random.Random(seed)
     return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
@@ -236,3 +228,19 @@ def test_two_engines_and_reuse_after_error():
             e1.prim(999, np.zeros((1, 4), dtype=np.uint64))
         assert np.array_equal(e1.mul_endo_fixed(s, t1), a) and np.array_equal(e2.mul_windowed_fixed(s, t2), b)
         assert np.array_equal(a, oc.mul(oc.ENDO, s, None, t1)) and np.array_equal(b, oc.mul(oc.WINDOWED, s, None, t2))
+
+
+def test_ct_select_from_the_environment(monkeypatch):
+    """FOURQ_CT_SELECT=1 at context creation turns the constant-time selection on for every entry point of that context."""
+    from fourq_amd import Engine
+    monkeypatch.setenv("FOURQ_CT_SELECT", "1")
+    with Engine(0) as e:
+        assert e.ct_select
+        s = seeded_scalars(77, 700)
+        pts = torsion_points(e, 78, 700)
+        assert np.array_equal(e.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
+        e.ct_select = False
+        assert not e.ct_select and np.array_equal(e.mul_windowed(s, pts), oc.mul(oc.WINDOWED, s, pts))
+    monkeypatch.delenv("FOURQ_CT_SELECT")
+    with Engine(0) as e:
+        assert not e.ct_select

@@ -24,14 +24,6 @@ G = (o.Gx, o.Gy)
 G1 = o.AffineToR1(o.Gx, o.Gy)
 
 
-@pytest.fixture(scope="module")
-def eng():
-    from fourq_amd import Engine
-    e = Engine(0)
-    yield e
-    e.close()
-
-
 def seeded_scalars(seed, n):
     rng = random.Random(seed)
     return np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
