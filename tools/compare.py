@@ -87,38 +87,51 @@ def print_ops(rows):
         print("%-22s %8d %8d %8g %4d" % (name, M, S, A, I))
 
 
-def timing_table(n=1 << 16, cpu_ops=20):
+def timing_table(n=1 << 16, cpu_ops=20, out=print):
+    """The reference's timing table (compare.py:171-219) with the MI355X engine in the second column.  Every GPU result
+    whose operation is timed is also CHECKED: the first `cpu_ops` elements of each batch are the operations the oracle
+    is timed on, and their outputs must be bit-identical.  Returns [(name, oracle s/op, GPU s/op, elements checked)]."""
     import numpy as np
     from fourq_amd import Engine, codec
-    rng = random.Random(2)
     G1, Gaff = o.AffineToR1(o.Gx, o.Gy), (o.Gx, o.Gy)
-    ms = [rng.getrandbits(256) for _ in range(cpu_ops)]
     raw = np.frombuffer(random.Random(3).getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+    ms = codec.unpack_scalars(raw[:cpu_ops])
+    rows = []
     with Engine(0) as eng:
         g1 = codec.pack_point(G1)
         te, tw = eng.table_endo(g1), eng.table_windowed(g1)
-        pts = eng.mul_endo_fixed(raw, te)
-        P = codec.unpack_fp2s(pts[0])
+        pts = eng.mul_endo_fixed(random_scalars(4, n), te)
+        Ps = codec.unpack_points(pts[:cpu_ops])
         gaff = np.repeat(codec.pack_point(Gaff).reshape(1, 8), n, axis=0)
+        Tw, Te = o.table_windowed(G1), o.table_endo(G1)
+        dh = lambda fn: (lambda: fn(raw, gaff)[0])
         cases = [
-            ("MUL_windowed(m,P)", lambda m: o.MUL_windowed(m, P), lambda: eng.mul_windowed(raw, pts)),
-            ("MUL_windowed(m,G,table)", lambda m, T=o.table_windowed(G1): o.MUL_windowed(m, G1, T), lambda: eng.mul_windowed_fixed(raw, tw)),
-            ("MUL_endo(m,P)", lambda m: o.MUL_endo(m, P), lambda: eng.mul_endo(raw, pts)),
-            ("MUL_endo(m,G,table)", lambda m, T=o.table_endo(G1): o.MUL_endo(m, G1, T), lambda: eng.mul_endo_fixed(raw, te)),
-            ("DH_windowed(m,G)", lambda m: o.DH_windowed(m, Gaff), lambda: eng.dh_windowed(raw, gaff)),
-            ("DH_endo(m,G)", lambda m: o.DH_endo(m, Gaff), lambda: eng.dh_endo(raw, gaff)),
+            ("MUL_windowed(m,P)", lambda m, P: o.MUL_windowed(m, P), lambda: eng.mul_windowed(raw, pts)),
+            ("MUL_windowed(m,G,table)", lambda m, P: o.MUL_windowed(m, G1, Tw), lambda: eng.mul_windowed_fixed(raw, tw)),
+            ("MUL_endo(m,P)", lambda m, P: o.MUL_endo(m, P), lambda: eng.mul_endo(raw, pts)),
+            ("MUL_endo(m,G,table)", lambda m, P: o.MUL_endo(m, G1, Te), lambda: eng.mul_endo_fixed(raw, te)),
+            ("DH_windowed(m,G)", lambda m, P: o.DH_windowed(m, Gaff), dh(eng.dh_windowed)),
+            ("DH_endo(m,G)", lambda m, P: o.DH_endo(m, Gaff), dh(eng.dh_endo)),
         ]
-        print("%-26s %16s %22s %10s" % ("operation", "oracle ms/op (1 core)", "MI355X us/op (batch 2^%d, PCIe incl.)" % (n.bit_length() - 1), "ratio"))
+        out("%-26s %16s %22s %10s" % ("operation", "oracle ms/op (1 core)", "MI355X us/op (batch 2^%d, PCIe incl.)" % (n.bit_length() - 1), "ratio"))
         for name, cpu, gpu in cases:
             t0 = time.perf_counter()
-            for m in ms:
-                cpu(m)
+            want = [cpu(m, P) for m, P in zip(ms, Ps)]
             c = (time.perf_counter() - t0) / len(ms)
             gpu()
             t0 = time.perf_counter()
-            gpu()
+            got = gpu()
             g = (time.perf_counter() - t0) / n
-            print("%-26s %16.3f %22.4f %10.0f" % (name, c * 1e3, g * 1e6, c / g))
+            if codec.unpack_points(got[:cpu_ops]) != want:
+                raise SystemExit("PARITY FAILURE in the timing table: %s" % name)
+            out("%-26s %16.3f %22.4f %10.0f" % (name, c * 1e3, g * 1e6, c / g))
+            rows.append((name, c, g, len(want)))
+    return rows
+
+
+def random_scalars(seed, n):
+    import numpy as np
+    return np.frombuffer(random.Random(seed).getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
 
 
 if __name__ == "__main__":
