@@ -444,7 +444,12 @@ def self_launch(args, argv):
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    return subprocess.run(cmd, env=env).returncode
+    # stdout carries rank 0's JSON line and nothing else: whatever the ranks' libraries print there (gloo's connection
+    # banner in rehearsals) is passed on to stderr
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        print(line, file=sys.stdout if line.startswith('{"metric"') else sys.stderr, flush=True)
+    return proc.returncode
 
 
 def main():

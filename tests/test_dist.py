@@ -69,16 +69,16 @@ def test_two_rank_shard_and_gather_gloo(tmp_path, n):
     assert np.array_equal(np.load(out), want)
 
 
-def test_bench_gpus_n_launches_its_own_ranks_before_touching_a_gpu(monkeypatch):
+def test_bench_gpus_n_launches_its_own_ranks_before_touching_a_gpu(monkeypatch, capsys):
     """`python bench.py --gpus N` from a bare shell: the parent builds a torch.distributed.run command on 127.0.0.1 with
     a free port, relays the children's return code and never initialises the GPU runtime itself."""
     import types
     import bench
     seen = {}
 
-    def fake_run(cmd, env=None):
+    def fake_run(cmd, env=None, stdout=None, text=None):
         seen["cmd"], seen["env"] = cmd, env
-        return types.SimpleNamespace(returncode=7)
+        return types.SimpleNamespace(returncode=7, stdout='[Gloo] Rank 0 is connected\n{"metric": "x", "value": 1}\n')
 
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
     for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -87,6 +87,8 @@ def test_bench_gpus_n_launches_its_own_ranks_before_touching_a_gpu(monkeypatch):
     with pytest.raises(SystemExit) as ei:
         bench.main()
     assert ei.value.code == 7
+    captured = capsys.readouterr()
+    assert captured.out == '{"metric": "x", "value": 1}\n' and "[Gloo]" in captured.err      # stdout = the one JSON line
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
     assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
