@@ -34,13 +34,16 @@ def is_stale():
     return any(os.path.getmtime(os.path.normpath(d)) > built for d in deps)
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
-    """Compile the library if it is missing or older than its sources; returns its path."""
-    if not force and not is_stale():
+def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
+    """Compile the library if it is missing or older than its sources; returns its path.  `out_path` + `extra_flags`
+    build an experiment variant beside the product library (tools/ab_bench.sh compares them on one GPU box)."""
+    if out_path is None and not force and not is_stale():
         return LIB_PATH
+    lib_path = out_path or LIB_PATH
+    suffix = "" if out_path is None else "." + os.path.splitext(os.path.basename(out_path))[0]
     objs, procs = [], []
     for src in SOURCES:                                   # compile the translation units in parallel (~1 min each)
-        obj = os.path.join(SRC_DIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(SRC_DIR, os.path.splitext(src)[0] + suffix + ".o")
         cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(SRC_DIR, src)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
@@ -50,14 +53,18 @@ def build_library(force=False, verbose=False, extra_flags=()):
         out, _ = proc.communicate()
         if proc.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(link), file=sys.stderr)
     proc = subprocess.run(link, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError("link failed:\n" + proc.stdout + proc.stderr)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    # python -m fourq_amd.build [--force] [--out variants/libX.so -DFLAG=1 ...]
+    argv = sys.argv[1:]
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    flags = [a for a in argv if a.startswith("-D") or a.startswith("-m")]
+    print(build_library(force="--force" in argv, verbose=True, extra_flags=flags, out_path=os.path.abspath(out) if out else None))

@@ -344,6 +344,55 @@ template <typename P> FQ_DEV void store_r2_limbs(P* dst, const R2& t) {
     store_fe2_limbs(dst + 2 * COORD_U32, t.E); store_fe2_limbs(dst + 3 * COORD_U32, t.F);
 }
 
+// Slot layouts of a per-lane table in HBM scratch.  A ladder step gathers one entry per lane, so the entry's size in
+// 64-byte memory sectors is the traffic of the step:
+//   LimbSlots    4 coordinates x 48 bytes, ready-to-use limbs: 192 bytes = 3 sectors (also the LDS layout)
+//   PackedSlots  4 coordinates x 32 bytes, each GF(p) element as one 128-bit word (value < 2^128, not necessarily
+//                canonical): 128 bytes = 2 sectors, at the price of 8 cheap ALU ops per element on every load.
+// (160 bytes of bare limbs would still straddle 3 sectors.)  PARK_P / PARK_Q: where table_endo parks its working points.
+struct LimbSlots {
+    static constexpr int COORD = COORD_U32, ENTRY = R2_LIMBS, PARK_P = 8 * R2_LIMBS, PARK_Q = 8 * R2_LIMBS + 40, SLOT = 464;
+    template <typename P> static FQ_DEV Fe2<1> load(const P* src) { return load_fe2_limbs(src); }
+    template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) { store_fe2_limbs(dst, v); }
+};
+// tight limbs (after fe_carry) -> one 128-bit word: fold bits >= 127 (2^127 == 1), ripple once, concatenate
+FQ_DEV uint4 fe_pack128(const Fe<1>& a) {
+    u32 l0 = a.l[0] + (a.l[4] >> 23), l1 = a.l[1], l2 = a.l[2], l3 = a.l[3], l4 = a.l[4] & 0x7fffff;
+    l1 += l0 >> LIMB_BITS; l0 &= LIMB_MASK;
+    l2 += l1 >> LIMB_BITS; l1 &= LIMB_MASK;
+    l3 += l2 >> LIMB_BITS; l2 &= LIMB_MASK;
+    l4 += l3 >> LIMB_BITS; l3 &= LIMB_MASK;              // l4 <= 2^23: the value is < 2^128
+    return make_uint4(l0 | (l1 << 26), (l1 >> 6) | (l2 << 20), (l2 >> 12) | (l3 << 14), (l3 >> 18) | (l4 << 8));
+}
+FQ_DEV Fe<1> fe_unpack128(const uint4& w) {
+    Fe<1> r;
+    r.l[0] = w.x & LIMB_MASK;
+    r.l[1] = __builtin_amdgcn_alignbit(w.y, w.x, 26) & LIMB_MASK;
+    r.l[2] = __builtin_amdgcn_alignbit(w.z, w.y, 20) & LIMB_MASK;
+    r.l[3] = __builtin_amdgcn_alignbit(w.w, w.z, 14) & LIMB_MASK;
+    r.l[4] = w.w >> 8;                                   // 24 bits
+    return r;
+}
+struct PackedSlots {
+    static constexpr int COORD = 8, ENTRY = 32, PARK_P = 8 * 32, PARK_Q = 8 * 32 + 32, SLOT = 320;
+    template <typename P> static FQ_DEV Fe2<1> load(const P* src) {
+        const uint4* q = reinterpret_cast<const uint4*>(src);
+        Fe2<1> r; r.re = fe_unpack128(q[0]); r.im = fe_unpack128(q[1]); return r;
+    }
+    template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) {
+        uint4* q = reinterpret_cast<uint4*>(dst);
+        q[0] = fe_pack128(v.re); q[1] = fe_pack128(v.im);
+    }
+};
+template <typename L, typename P> FQ_DEV R2 load_r2(const P* src) {
+    R2 t;
+    t.N = L::load(src); t.D = L::load(src + L::COORD); t.E = L::load(src + 2 * L::COORD); t.F = L::load(src + 3 * L::COORD);
+    return t;
+}
+template <typename L, typename P> FQ_DEV void store_r2(P* dst, const R2& t) {
+    L::store(dst, t.N); L::store(dst + L::COORD, t.D); L::store(dst + 2 * L::COORD, t.E); L::store(dst + 3 * L::COORD, t.F);
+}
+
 template <int CH, int A, int B> FQ_DEV auto fe2_subx(const Fe2<A>& a, const Fe2<B>& b) {
     if constexpr (CH == 2) return widen<A + B + 1>(fe2_sub_signed(a, b)); else return fe2_sub(a, b);
 }
@@ -354,15 +403,15 @@ template <int CH, int B> FQ_DEV auto fe2_cnegx(const Fe2<B>& x, u32 mask) {
 // ADD(Q, selectpt(s, T, R2neg(T))) of curve4q.py:232-233, :440 with R2neg(T) = (D, N, E, -F).  The N/D swap
 // of the negated entry is an address choice, -F is a two-op conditional negation, and each coordinate
 // is loaded just before the product that consumes it, which keeps the live set near 100 VGPRs.
-template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_mask) {
-    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename L = LimbSlots, typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_mask) {
+    const int off_n = neg_mask ? L::COORD : 0, off_d = neg_mask ? 0 : L::COORD;
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);                          // R1toR3: curve4q.py:119-126
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
-    Fe2<1> A = fe2_mulx<CH>(D1, load_fe2_limbs(entry + off_d));    // ADD_core: curve4q.py:155-171
-    Fe2<1> B = fe2_mulx<CH>(N1, load_fe2_limbs(entry + off_n));
-    Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(load_fe2_limbs(entry + 3 * COORD_U32), neg_mask), T);
-    Fe2<1> D = fe2_mulx<CH>(load_fe2_limbs(entry + 2 * COORD_U32), q.Z);
+    Fe2<1> A = fe2_mulx<CH>(D1, L::load(entry + off_d));           // ADD_core: curve4q.py:155-171
+    Fe2<1> B = fe2_mulx<CH>(N1, L::load(entry + off_n));
+    Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(L::load(entry + 3 * L::COORD), neg_mask), T);
+    Fe2<1> D = fe2_mulx<CH>(L::load(entry + 2 * L::COORD), q.Z);
     Fe2<3> E = fe2_subx<CH>(B, A);
     Fe2<3> F = fe2_subx<CH>(D, C);
     Fe2<2> G = fe2_add(D, C);
@@ -380,11 +429,11 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_table(cons
 struct EntryRegs {
     Fe2<1> N, D, E, F;
 };
-template <typename P> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask) {
-    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
+template <typename L = LimbSlots, typename P> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask) {
+    const int off_n = neg_mask ? L::COORD : 0, off_d = neg_mask ? 0 : L::COORD;
     EntryRegs t;
-    t.N = load_fe2_limbs(entry + off_n); t.D = load_fe2_limbs(entry + off_d);
-    t.E = load_fe2_limbs(entry + 2 * COORD_U32); t.F = load_fe2_limbs(entry + 3 * COORD_U32);
+    t.N = L::load(entry + off_n); t.D = L::load(entry + off_d);
+    t.E = L::load(entry + 2 * L::COORD); t.F = L::load(entry + 3 * L::COORD);
     return t;
 }
 template <int CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_mask) {
@@ -502,16 +551,14 @@ template <int ENTRIES, typename TP> struct ScanMem {
 };
 template <int ENTRIES, int COORDS> struct ScanRegs {
     u32 w[ENTRIES][COORDS * 10];
-    template <typename TP> FQ_DEV void load(const TP* tbl, int stride) {
+    template <typename L, typename TP> FQ_DEV void load(const TP* tbl) {     // the lane's table, in slot layout L
 #pragma unroll
         for (int k = 0; k < ENTRIES; k++) {
 #pragma unroll
             for (int c = 0; c < COORDS; c++) {
-                const uint4* q = reinterpret_cast<const uint4*>(tbl + k * stride + c * COORD_U32);
-                const uint4 a = q[0], b = q[1], d = q[2];
-                const u32 v[10] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y };
+                const Fe2<1> v = L::load(tbl + k * L::ENTRY + c * L::COORD);
 #pragma unroll
-                for (int i = 0; i < 10; i++) w[k][c * 10 + i] = v[i];
+                for (int i = 0; i < 5; i++) { w[k][c * 10 + i] = v.re.l[i]; w[k][c * 10 + 5 + i] = v.im.l[i]; }
             }
         }
     }
@@ -596,13 +643,13 @@ template <typename SRC> FQ_DEV R1 affine_scan_start(const SRC& src, u32 idx, u32
 }
 
 // R2toR4(selectpt(s, T, nT)): the ladder's starting point (curve4q.py:229, :437)
-template <typename P> FQ_DEV Proj<1, 1, 1> start_table(const P* entry, u32 neg_mask) {
-    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
-    Fe2<1> N = load_fe2_limbs(entry + off_n), D = load_fe2_limbs(entry + off_d);
+template <typename L = LimbSlots, typename P> FQ_DEV Proj<1, 1, 1> start_table(const P* entry, u32 neg_mask) {
+    const int off_n = neg_mask ? L::COORD : 0, off_d = neg_mask ? 0 : L::COORD;
+    Fe2<1> N = L::load(entry + off_n), D = L::load(entry + off_d);
     Proj<1, 1, 1> r;
     r.X = fe2_carry(fe2_sub(N, D));
     r.Y = fe2_carry(fe2_add(D, N));
-    r.Z = load_fe2_limbs(entry + 2 * COORD_U32);
+    r.Z = L::load(entry + 2 * L::COORD);
     return r;
 }
 

@@ -35,9 +35,13 @@ using namespace fq;
 namespace {
 
 // packed table (8 x 16 words) -> working limbs (8 x 48 u32)
-__global__ void table_unpack_kernel(const u64* packed, u32* limbs) {
+__global__ void table_unpack_kernel(const u64* packed, u32* limbs, u32* slots) {
     int k = threadIdx.x;
-    if (k < 8) store_r2_limbs(limbs + k * R2_LIMBS, load_r2_packed(packed + 16 * k));
+    if (k < 8) {
+        const R2 t = load_r2_packed(packed + 16 * k);
+        store_r2_limbs(limbs + k * R2_LIMBS, t);
+        store_r2<PrebuiltSlots>(slots + k * PrebuiltSlots::ENTRY, t);     // what a mixed batch's per-lane pointer reads
+    }
 }
 // working limbs of one lane's scratch slot -> packed table
 __global__ void table_build_kernel(int algo, const u64* p_r1, u32* scratch, u64* packed) {
@@ -320,9 +324,11 @@ struct fourq_ctx {
     size_t lanes_w4 = 0;           // resident lanes of the 128-VGPR kernels (4 waves per SIMD)
     size_t split_min = 0;          // variable-base batches of at least this many elements take the prep + ladder route
     size_t split_chunk = 0;        // elements per prep + ladder round (<= lanes_w4)
-    bool split_all = false;        // FOURQ_SPLIT_ALL=1: also route plain MUL_endo through prep + ladder (tests)
+    bool split_all = false;        // FOURQ_SPLIT_ALL=1: route plain MUL_endo through prep + ladder from split_min on (tests)
+    size_t split_endo_min = 0;     // plain MUL_endo batches of at least this many elements take prep + ladder (0: never)
     u32* scratch = nullptr;        // max(lanes, lanes_w4) x SLOT_U32
-    u32* table_limbs = nullptr;    // 8 x 40
+    u32* table_limbs = nullptr;    // 8 x 48: the staged fixed-base table as working limbs
+    u32* table_slots = nullptr;    // the same in the PrebuiltSlots layout
     u64* table_packed = nullptr;   // 128 words
     u32* comb_limbs = nullptr;     // 80 x 36 working limbs of the staged comb table
     u64* comb_packed = nullptr;    // 80 x 12 words
@@ -388,6 +394,7 @@ template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs
     unsigned grid = (unsigned)(blocks_needed < blocks_max ? blocks_needed : blocks_max);
     a.scratch = c->scratch;
     a.table = c->table_limbs;
+    a.table_slots = c->table_slots;
     if (c->ct) {                            // constant-time selection: fourq_ct_fused.hip / fourq_ct_chain.hip
         if (SRC == PREBUILT) return FOURQ_ERR_INVALID;    // the two-kernel route is not taken in this mode
         HIPRC_TRY(c, SRC == FUSED ? ct_launch_fused(ALGO, DH, grid, c->stream, a) : ct_launch_lds(ALGO, DH, grid, c->stream, a));
@@ -399,12 +406,15 @@ template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs
     }
     return FOURQ_OK;
 }
-// Measured on MI355X at 2^20 elements: the two-kernel route gains for MUL_windowed and DH_* and is on par for
-// plain MUL_endo, whose 64-step ladder hardly amortises the second launch and the colder table gathers (4 waves
-// per SIMD put 486 MB of tables in flight, past the Infinity Cache); plain MUL_endo therefore stays fused.
+// Which variable-base batches take the two-kernel route (prep_kernel + ladder_kernel<PREBUILT>, 4 waves per SIMD).
+// Measured on MI355X with packed 128-byte table entries (profiles/r02_split_route.txt): MUL_windowed and DH_* gain
+// 2-8 % from two resident generations of the fused kernels upwards; plain MUL_endo, whose 64-step ladder hardly
+// amortises the second launch, gains 1-3 % from four generations upwards and nothing below.  (With 192-byte entries a
+// round's tables, 486 MB, fell out of the Infinity Cache and plain MUL_endo lost 7 % on this route.)
 bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
     if (c->ct) return false;        // constant-time mode keeps the lane's table in registers: fused kernels only
-    return (algo == WINDOWED || dh || c->split_all) && n >= c->split_min;
+    if (algo == WINDOWED || dh || c->split_all) return n >= c->split_min;
+    return c->split_endo_min && n >= c->split_endo_min;
 }
 template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
     if (!takes_split_route(c, ALGO, DH, a.n)) return launch_ladder<ALGO, FUSED, DH>(c, a);
@@ -444,7 +454,7 @@ int stage_table(fourq_ctx* c, const uint64_t* table_host) {
     c->table_staged = false;
     memcpy(c->table_shadow, table_host, sizeof c->table_shadow);
     HIP_TRY(c, hipMemcpyAsync(c->table_packed, c->table_shadow, FOURQ_TABLE_WORDS * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(table_unpack_kernel, dim3(1), dim3(64), 0, c->stream, c->table_packed, c->table_limbs);
+    hipLaunchKernelGGL(table_unpack_kernel, dim3(1), dim3(64), 0, c->stream, c->table_packed, c->table_limbs, c->table_slots);
     HIP_TRY(c, hipGetLastError());
     c->table_staged = true;
     return FOURQ_OK;
@@ -642,7 +652,9 @@ int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* po
     DeviceGuard g(c->device);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points, nullptr, 160 } };
     PipeArray o[1] = { { nullptr, (char*)out, 160 } };
-    const bool fused = points && !takes_split_route(c, algo, false, n);
+    // variable-base MUL_endo: chunks of one fused generation overlap the copies better than rounds of the two-kernel route
+    // would (16 chunks instead of 4 at 2^20 elements: 6.7 ms against ~7.8)
+    const bool fused = points && (algo == ENDO || !takes_split_route(c, algo, false, n));
     return run_pipeline(c, in, points ? 2 : 1, o, 1, n, pipe_chunk(c, fused), [&](char* const* di, char* const* dout, size_t m) {
         return mul_dev(c, algo, (const uint64_t*)di[0], points ? (const uint64_t*)di[1] : nullptr, table, (uint64_t*)dout[0], nullptr, m);
     });
@@ -728,6 +740,8 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         c->split_min = 2 * c->lanes;                       // below two full waves of fused work the second launch does not pay
         if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
+        c->split_endo_min = 4 * c->lanes;
+        if (const char* env = getenv("FOURQ_SPLIT_ENDO_MIN")) { long v = atol(env); if (v >= 0) c->split_endo_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
@@ -736,6 +750,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         size_t slots = c->lanes > c->lanes_w4 ? c->lanes : c->lanes_w4;
         if (hipMalloc(&c->scratch, slots * SLOT_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->table_slots, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_counter, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_fix, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
@@ -756,6 +771,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->proj) (void)hipFree(c->proj);
     if (c->table_limbs) (void)hipFree(c->table_limbs);
+    if (c->table_slots) (void)hipFree(c->table_slots);
     if (c->table_packed) (void)hipFree(c->table_packed);
     if (c->part_counter) (void)hipFree(c->part_counter);
     if (c->part_list) (void)hipFree(c->part_list);
@@ -890,7 +906,7 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
         HIP_TRY(c, hipGetLastError());
         LadderArgs a = {};
         a.scalars = s; a.points = p; a.out = o; a.n = m;
-        a.scratch = c->scratch; a.table = c->table_limbs;
+        a.scratch = c->scratch; a.table = c->table_limbs; a.table_slots = c->table_slots;
         if (c->ct) {
             // constant-time selection: which elements are fixed-base is public, the digits are not.  The variable-base
             // ids go through the fused kernel (table in registers), the fixed-base ids through the LDS kernel; both

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/fourq_amd.h"
 #include "curve.hip.h"
@@ -16,8 +17,29 @@
 namespace fq {
 
 constexpr int BLOCK = 256;
-constexpr int SLOT_U32 = 464;          // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
-constexpr int SLOT_P = 384, SLOT_Q = 424;
+constexpr int SLOT_U32 = LimbSlots::SLOT;   // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
+constexpr int SLOT_P = LimbSlots::PARK_P, SLOT_Q = LimbSlots::PARK_Q;
+// Layout of the slots that prep_kernel fills and ladder_kernel<PREBUILT> gathers from: 2^18 elements in flight make
+// 486 MB of 192-byte entries, past the 256 MiB Infinity Cache, and the DH ladder of BASELINE config 4 then pulls
+// 4 TB/s from HBM; packed 128-byte entries cut that by a third and let a round's tables stay in the cache.
+#ifndef FQ_PREBUILT_PACKED
+#define FQ_PREBUILT_PACKED 1
+#endif
+#if FQ_PREBUILT_PACKED
+typedef PackedSlots PrebuiltSlots;
+#else
+typedef LimbSlots PrebuiltSlots;
+#endif
+// The fused kernels (one wave per SIMD, 2^16 slots = 122 MB: always inside the Infinity Cache) keep ready-to-use limbs
+// unless measurement says otherwise.
+#ifndef FQ_FUSED_PACKED
+#define FQ_FUSED_PACKED 0
+#endif
+#if FQ_FUSED_PACKED
+typedef PackedSlots FusedSlots;
+#else
+typedef LimbSlots FusedSlots;
+#endif
 constexpr int PROJ_PLANES = 8;            // deferred normalisation: the 30 working limbs of (X, Y, Z) in eight uint4 planes
 constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
 
@@ -39,6 +61,7 @@ struct LadderArgs {
     const u32* n_dev;      // optional: element count read on the device (mixed batches: no host round trip)
     const u32* slot_of;    // PREBUILT, optional (mixed batches): per position, the scratch slot of its table or ~0 = `table`
     const u32* table;      // fixed base: 8 x 48 working limbs (global), staged to LDS
+    const u32* table_slots;// the same table in the PrebuiltSlots layout (mixed batches: read through a per-lane pointer)
     u32* scratch;          // variable base: SLOT_U32 per resident lane (FUSED) or per position of the chunk (PREBUILT)
     uint4* proj;           // DH, optional: PROJ_PLANES x proj_stride; non-NULL selects the kernels that leave (X, Y, Z)
                            // there for normalize_kernel (always the case on the PREBUILT route)
@@ -93,14 +116,14 @@ FQ_DEV void load_proj_xy(const uint4* proj, u32 stride, u32 id, Fe2<1>& X, Fe2<1
 }
 
 // T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                       curve4q.py:179-185
-FQ_DEV void build_table_windowed(const R1& P, u32* tbl) {
+template <typename L = LimbSlots> FQ_DEV void build_table_windowed(const R1& P, u32* tbl) {
     R3 twoP = r1_to_r3(dbl(P));
     R2 t = r1_to_r2(P);
-    store_r2_limbs(tbl, t);
+    store_r2<L>(tbl, t);
 #pragma unroll 1
     for (int i = 1; i < 8; i++) {
         t = r1_to_r2(add_core(twoP, as_signed(t)));
-        store_r2_limbs(tbl + i * R2_LIMBS, t);
+        store_r2<L>(tbl + i * L::ENTRY, t);
     }
 }
 
@@ -110,8 +133,9 @@ FQ_DEV void build_table_windowed(const R1& P, u32* tbl) {
 //   step 2: S = psi(Q) -> T[4..7] = S + T[0..3]
 // tau and tau_dual are shared by the three steps (one code instance each): the working points P and
 // Q are parked in the lane's scratch slot so that they do not pin 60 VGPRs across the endomorphisms.
-FQ_DEV void build_table_endo(const R1& P, u32* slot) {
-    store_r2_limbs(slot, r1_to_r2(P));
+template <typename L = LimbSlots> FQ_DEV void build_table_endo(const R1& P, u32* slot) {
+    constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
+    store_r2<L>(slot, r1_to_r2(P));
     store_xyz(slot + SLOT_P, P.X, P.Y, P.Z);
 #pragma unroll 1
     for (int step = 0; step < 3; step++) {
@@ -137,8 +161,8 @@ FQ_DEV void build_table_endo(const R1& P, u32* slot) {
         int half = 1 << step;
 #pragma unroll 1
         for (int m = 0; m < half; m++) {
-            R2 base = load_r2_limbs(slot + m * R2_LIMBS);
-            store_r2_limbs(slot + (half + m) * R2_LIMBS, r1_to_r2(add_core(V3, as_signed(base))));
+            R2 base = load_r2<L>(slot + m * L::ENTRY);
+            store_r2<L>(slot + (half + m) * L::ENTRY, r1_to_r2(add_core(V3, as_signed(base))));
         }
     }
 }
@@ -174,27 +198,27 @@ template <int CH> FQ_DEV R1 ladder_result(const R1& Q) {
         return Q;
     }
 }
-template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
-    Proj<1, 1, 1> q4 = start_table(tbl + (e.top & 7) * stride, 0u);        // s[64] = 1: the entry itself
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
+    Proj<1, 1, 1> q4 = start_table<L>(tbl + (e.top & 7) * stride, 0u);        // s[64] = 1: the entry itself
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
         const TP* entry = tbl + endo_digit(e, i) * stride;
         if (PRELOAD) {
             const u32 neg = endo_neg_mask(e, i);
-            EntryRegs t = load_entry(entry, neg);
+            EntryRegs t = load_entry<L>(entry, neg);
             Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_entry<CH>(Q, t, neg);
         } else {
             Q = dbl<CH>(Q.X, Q.Y, Q.Z);
-            Q = add_table<CH>(Q, entry, endo_neg_mask(e, i));
+            Q = add_table<CH, L>(Q, entry, endo_neg_mask(e, i));
         }
     }
     return ladder_result<CH>(Q);
 }
-template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
-    Proj<1, 1, 1> q4 = start_table(tbl + (code & 7) * stride, (code >> 3) - 1u);
+    Proj<1, 1, 1> q4 = start_table<L>(tbl + (code & 7) * stride, (code >> 3) - 1u);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
@@ -202,14 +226,14 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename TP> F
         const TP* entry = tbl + (code & 7) * stride;
         const u32 neg = (code >> 3) - 1u;
         if (PRELOAD) {
-            EntryRegs t = load_entry(entry, neg);
+            EntryRegs t = load_entry<L>(entry, neg);
 #pragma unroll 1
             for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_entry<CH>(Q, t, neg);
         } else {
 #pragma unroll 1
             for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
-            Q = add_table<CH>(Q, entry, neg);
+            Q = add_table<CH, L>(Q, entry, neg);
         }
     }
     return ladder_result<CH>(Q);
@@ -253,14 +277,15 @@ FQ_DEV void memory_point() {
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0); expcnt and lgkmcnt untouched
     __builtin_amdgcn_sched_barrier(0);
 }
-FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot) {
+template <typename L = LimbSlots> FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot) {
+    constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
     R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
     int result_at = 0;
     Fe2<1> X = P.X, Y = P.Y, Z = P.Z;          // step 0: P; step 1: tau(P), parked by step 0; step 2: phi(P)
 #pragma unroll 1
     for (int step = 0; step < 3; step++) {
         memory_point();                        // X, Y, Z (requested during the previous additions) are here
-        store_r2_limbs(slot + result_at * R2_LIMBS, result);
+        store_r2<L>(slot + result_at * L::ENTRY, result);
         __builtin_amdgcn_sched_barrier(0);
         Proj<1, 2, 1> t;
         if (step == 1) {                       // phi and psi share tau(P), curve4q.py:318-322
@@ -277,7 +302,7 @@ FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot) {
             u.X = widen<2>(c.X); u.Y = widen<2>(c.Y); u.Z = widen<2>(c.Z);
         }
         memory_point();                        // request T[0] one isogeny before the first addition
-        R2 base = load_r2_limbs(slot);
+        R2 base = load_r2<L>(slot);
         __builtin_amdgcn_sched_barrier(0);
         R1 V = tau_dual(u.X, u.Y, u.Z);
         R3 V3 = r1_to_r3(V);
@@ -285,9 +310,9 @@ FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot) {
 #pragma unroll 1
         for (int m = 0; m < half; m++) {
             memory_point();                    // `base` is here; whatever was stored last is acknowledged
-            if (m > 0) store_r2_limbs(slot + result_at * R2_LIMBS, result);
+            if (m > 0) store_r2<L>(slot + result_at * L::ENTRY, result);
             R2 next = base;
-            if (m + 1 < half) next = load_r2_limbs(slot + (m + 1) * R2_LIMBS);
+            if (m + 1 < half) next = load_r2<L>(slot + (m + 1) * L::ENTRY);
             if (m == 0 && step == 0) store_xyz(slot + SLOT_Q, V.X, V.Y, V.Z);
             if (m == half - 1 && step < 2) load_xyz(slot + (step == 0 ? SLOT_P : SLOT_Q), X, Y, Z);   // for the next step
             __builtin_amdgcn_sched_barrier(0);
@@ -296,8 +321,43 @@ FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot) {
             base = next;
         }
     }
-    store_r2_limbs(slot + result_at * R2_LIMBS, result);     // T[7]; the ladder's first gather waits for it
+    store_r2<L>(slot + result_at * L::ENTRY, result);     // T[7]; the ladder's first gather waits for it
 }
+
+// Experiment (FQ_TABLE_INTERLEAVE=1): the same table as straight-line code with the independent parts side by side --
+// phi(P) beside psi(P) behind the shared tau(P); psi(phi(P)) beside the three additions that do not need it; the last four
+// additions together -- so that a lone wave always has a second dependency chain to issue from.  Same DAG, same entries.
+template <typename L = LimbSlots> FQ_DEV void build_table_endo_interleaved(const R1& P, u32* slot) {
+    const R2 T0 = r1_to_r2(P);
+    store_r2<L>(slot, T0);
+    const Proj<1, 2, 1> t = tau(P.X, P.Y, P.Z);
+    const Proj<2, 2, 2> u = upsilon(t);                                     // phi(P) = tau_dual(upsilon(tau(P)))
+    const Proj<1, 1, 1> c = chi(t);                                         // psi(P) = tau_dual(chi(tau(P)))
+    const R1 Vq = tau_dual(u.X, u.Y, u.Z);
+    const R1 Vr = tau_dual(widen<2>(c.X), widen<2>(c.Y), widen<2>(c.Z));
+    const Proj<1, 2, 1> t2 = tau(Vq.X, Vq.Y, Vq.Z);                          // psi(phi(P)) ...
+    const R3 q3 = r1_to_r3(Vq), r3 = r1_to_r3(Vr);
+    const R2 T1 = r1_to_r2(add_core(q3, as_signed(T0)));                    // ... beside T[1] = Q + T[0]
+    store_r2<L>(slot + 1 * L::ENTRY, T1);
+    const Proj<1, 1, 1> c2 = chi(t2);
+    const R2 T2 = r1_to_r2(add_core(r3, as_signed(T0)));                    //            T[2] = R + T[0]
+    store_r2<L>(slot + 2 * L::ENTRY, T2);
+    const R2 T3 = r1_to_r2(add_core(r3, as_signed(T1)));                    //            T[3] = R + T[1]
+    store_r2<L>(slot + 3 * L::ENTRY, T3);
+    const R1 Vs = tau_dual(widen<2>(c2.X), widen<2>(c2.Y), widen<2>(c2.Z));
+    const R3 s3 = r1_to_r3(Vs);
+    const R2 T4 = r1_to_r2(add_core(s3, as_signed(T0)));                    // T[4 + k] = S + T[k]: four independent additions
+    const R2 T5 = r1_to_r2(add_core(s3, as_signed(T1)));
+    const R2 T6 = r1_to_r2(add_core(s3, as_signed(T2)));
+    const R2 T7 = r1_to_r2(add_core(s3, as_signed(T3)));
+    store_r2<L>(slot + 4 * L::ENTRY, T4);
+    store_r2<L>(slot + 5 * L::ENTRY, T5);
+    store_r2<L>(slot + 6 * L::ENTRY, T6);
+    store_r2<L>(slot + 7 * L::ENTRY, T7);
+}
+#ifndef FQ_TABLE_INTERLEAVE
+#define FQ_TABLE_INTERLEAVE 0
+#endif
 
 FQ_DEV void load_scalar(const u64* p, u64 m[4]) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -324,8 +384,8 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
     } else {
         P = load_r1(a.points + 20 * (size_t)id);
     }
-    u32* slot = a.scratch + (size_t)pos * SLOT_U32;
-    if (ALGO == ENDO) build_table_endo(P, slot); else build_table_windowed(P, slot);
+    u32* slot = a.scratch + (size_t)pos * PrebuiltSlots::SLOT;
+    if (ALGO == ENDO) build_table_endo<PrebuiltSlots>(P, slot); else build_table_windowed<PrebuiltSlots>(P, slot);
 }
 
 // ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
@@ -352,11 +412,12 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
-        u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * SLOT_U32;
+        using L = typename std::conditional<SRC == PREBUILT, PrebuiltSlots, FusedSlots>::type;
+        u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * L::SLOT;
         const u32* tbl = slot;
         if (SRC == PREBUILT && a.slot_of) {                              // mixed batch: own table or the shared one
             const u32 own = a.slot_of[pos];
-            tbl = own == ~0u ? a.table : a.scratch + (size_t)own * SLOT_U32;
+            tbl = own == ~0u ? a.table_slots : a.scratch + (size_t)own * L::SLOT;
         }
 
         uint8_t st = FOURQ_DH_OK;
@@ -372,7 +433,11 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
                 P = load_r1(a.points + 20 * (size_t)id);
             }
             if (SRC == FUSED) {
-                if (ALGO == ENDO) build_table_endo_lone_wave(P, slot); else build_table_windowed(P, slot);
+                if (ALGO == ENDO) {
+                    if (FQ_TABLE_INTERLEAVE) build_table_endo_interleaved<L>(P, slot); else build_table_endo_lone_wave<L>(P, slot);
+                } else {
+                    build_table_windowed<L>(P, slot);
+                }
             }
         }
         R1 Q;
@@ -383,23 +448,25 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
             if constexpr (CT && SRC == FUSED) {
                 ScanRegs<8, 4> regs;
-                regs.load(tbl, R2_LIMBS);
+                regs.template load<L>(tbl);
                 Q = ladder_endo_scan<CH>(e, regs);
             } else if constexpr (CT) {
-                Q = SRC == LDS ? ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 }) : ladder_endo_scan<CH>(e, ScanMem<8, u32>{ tbl, R2_LIMBS });
+                static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
+                Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else
-            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(e, tbl, R2_LIMBS);
+            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(e, tbl, L::ENTRY);
         } else {
             WinScalar w = win_reduce(m);
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
             if constexpr (CT && SRC == FUSED) {
                 ScanRegs<8, 4> regs;
-                regs.load(tbl, R2_LIMBS);
+                regs.template load<L>(tbl);
                 Q = ladder_windowed_scan<CH>(w, regs);
             } else if constexpr (CT) {
-                Q = SRC == LDS ? ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 }) : ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ tbl, R2_LIMBS });
+                static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
+                Q = ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else
-            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD>(w, tbl, R2_LIMBS);
+            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(w, tbl, L::ENTRY);
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
             if (live) {

@@ -15,7 +15,8 @@ from fourq_amd import Engine, codec, constants
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--modes", default="endo_var,endo_fixed,win_var,win_fixed,dh_endo")
-ap.add_argument("--sizes", default="16,18,20")
+ap.add_argument("--sizes", default="16,18,20", help="log2 batch sizes")
+ap.add_argument("--ns", default="", help="explicit batch sizes (overrides --sizes)")
 ap.add_argument("--reps", type=int, default=5)
 args = ap.parse_args()
 
@@ -26,8 +27,8 @@ eng = Engine(0, stream=stream.cuda_stream)
 g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
 te, tw = eng.table_endo(g1), eng.table_windowed(g1)
 print("lib", os.environ.get("FOURQ_AMD_LIB", "default"), "lanes", eng.lanes, flush=True)
-for lg in [int(x) for x in args.sizes.split(",")]:
-    n = 1 << lg
+for n in ([int(x) for x in args.ns.split(",")] if args.ns else [1 << int(x) for x in args.sizes.split(",")]):
+    lg = n.bit_length() - 1
     s = torch.from_numpy(seeded_scalars(1, n).view(np.int64)).to(dev)
     k = torch.from_numpy(seeded_scalars(2, n).view(np.int64)).to(dev)
     pts = torch.empty((n, 20), dtype=torch.int64, device=dev)
@@ -59,4 +60,4 @@ for lg in [int(x) for x in args.sizes.split(",")]:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream); fn(); b.record(stream); torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b))
-        print("n=2^%d %-10s %8.3f ms  %8.2f Mmults/s" % (lg, mode, best, n / best / 1e3), flush=True)
+        print("n=%-8d (2^%d+%d) %-10s %8.3f ms  %8.2f Mmults/s" % (n, lg, n - (1 << lg), mode, best, n / best / 1e3), flush=True)
