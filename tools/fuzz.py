@@ -42,7 +42,13 @@ while time.time() < t_end:
         knobs["FOURQ_NORM_K"] = str(rng.choice([0, 2, 4, 8]))
         if rng.random() < 0.3:
             knobs["FOURQ_SPLIT_ALL"] = "1"
-    for k in ("FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL"):
+        if rng.random() < 0.3:
+            knobs["FOURQ_SPLIT_ENDO_MIN"] = str(rng.choice([0, 300, 70000]))
+    if rng.random() < 0.35:
+        knobs["FOURQ_CT_SELECT"] = "1"
+    if rng.random() < 0.3:
+        knobs["FOURQ_HOST_BOUNCE"] = "0"
+    for k in ("FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     with Engine(0) as eng:
@@ -60,9 +66,36 @@ while time.time() < t_end:
             if rng.random() < 0.2:
                 s[rng.randrange(n)] = 0
             pts = eng.mul_endo_fixed(scalars(n), te)
-            what = rng.choice(["endo", "win", "endo_fixed", "win_fixed", "mixed", "dh_endo", "dh_win", "dh_fixed", "comb"])
+            what = rng.choice(["endo", "win", "endo_fixed", "win_fixed", "mixed", "dh_endo", "dh_win", "dh_fixed", "comb", "pinned", "dh_bytes", "exchange"])
             if what == "endo":
                 ok = np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
+            elif what == "pinned":                           # the same from pinned host arrays (DMA in place, no bounce)
+                sp, pp, op_ = eng.host_array(s), eng.host_array(pts), eng.host_empty((n, 20))
+                ok = np.array_equal(eng.mul_windowed(sp, pp, out=op_), oc.mul(oc.WINDOWED, s, pts))
+                for a_ in (sp, pp, op_):
+                    eng.host_free(a_)
+            elif what in ("dh_bytes", "exchange"):
+                gg = np.repeat(gaff.reshape(1, 8), n, axis=0)
+                pub, st0 = oc.dh(oc.ENDO, scalars(n), gg)   # public keys DH(b, G)
+                if what == "dh_bytes":
+                    keys = eng.encode(pub)
+                    if n > 3:
+                        keys[rng.randrange(n), 15] |= 0x80  # a reserved bit: decode status 1
+                    got, gst = eng.dh_bytes(s, keys)
+                    dec, dst = eng.decode(keys)
+                    want, wst = oc.dh(oc.ENDO, s, dec)
+                    wst = np.where(dst != 0, 16 + dst, wst).astype(np.uint8)
+                    wenc = eng.encode(want)
+                    wenc[wst != 0] = 0
+                    ok = np.array_equal(got, wenc) and np.array_equal(gst, wst)
+                else:
+                    b2 = scalars(n)
+                    mid, s1 = oc.dh(oc.ENDO, b2, gg)
+                    want, s2 = oc.dh(oc.ENDO, s, mid)
+                    wst = np.where(s1 != 0, s1, s2)
+                    want[wst != 0] = 0
+                    got, gst = eng.dh_exchange(s, b2, gaff)
+                    ok = np.array_equal(got, want) and np.array_equal(gst, wst)
             elif what == "win":
                 ok = np.array_equal(eng.mul_windowed(s, pts), oc.mul(oc.WINDOWED, s, pts))
             elif what == "endo_fixed":

@@ -65,4 +65,31 @@ with Engine(0) as eng:
     ok = not dst.any() and np.array_equal(dec, a)
     print("%-28s n=2^%d  identical=%s" % ("decode(encode(P)) == P", LG, ok), flush=True)
     assert ok
+    # protocol-level calls (r02): keys and secrets as 32-byte strings, both halves of an exchange chained on the device
+    k2 = scalars(4)
+    t0 = time.time(); sec, sst = eng.dh_bytes(k2, enc); t1 = time.time()
+    want, wst = oc.dh(oc.ENDO, k2, b)
+    ok = not sst.any() and not wst.any() and np.array_equal(sec, eng.encode(want))
+    print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  identical=%s" % ("dh_bytes(k, encode(DH(m,G)))", LG, t1 - t0, ok), flush=True)
+    assert ok
+    t0 = time.time(); ex, est = eng.dh_exchange(k2, s, codec.pack_point((o.Gx, o.Gy))); t1 = time.time()
+    ok = not est.any() and np.array_equal(ex, want)
+    print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  identical=%s" % ("dh_exchange(k, m, G)", LG, t1 - t0, ok), flush=True)
+    assert ok
+    # the same multiplication from pinned host arrays and with constant-time table selection
+    sp, pp, op_ = eng.host_array(s), eng.host_array(pts), eng.host_empty((n, 20))
+    ref = oc.mul(oc.ENDO, s, pts)
+    t0 = time.time(); got = eng.mul_endo(sp, pp, out=op_); t1 = time.time()
+    st_ = eng.host_stats()
+    print("%-28s n=2^%d  GPU %.3fs (PCIe incl., %d chunks, %.0f / %.0f GB/s)  identical=%s" % ("MUL_endo, pinned arrays", LG, t1 - t0, st_["chunks"],
+          st_["gbs_h2d"], st_["gbs_d2h"], np.array_equal(got, ref)), flush=True)
+    assert np.array_equal(got, ref)
+    eng.ct_select = True
+    for name, gpu, cpu in (("MUL_endo, constant-time", lambda: eng.mul_endo(sp, pp, out=op_), lambda: ref),
+                           ("MUL_windowed fixed, constant-time", lambda: eng.mul_windowed_fixed(s, tw), lambda: oc.mul(oc.WINDOWED, s, None, tw)),
+                           ("comb keygen, constant-time", lambda: eng.comb_mul(s, comb)[0], lambda: b)):
+        t0 = time.time(); x = gpu(); t1 = time.time()
+        ok = np.array_equal(x, cpu())
+        print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  identical=%s" % (name, LG, t1 - t0, ok), flush=True)
+        assert ok
 print("SOAK OK")
