@@ -9,12 +9,14 @@
 //   variable base : the lane builds its own 8-entry R2 table (table_endo / table_windowed) into a 1 856-byte
 //                   slot of HBM scratch (192 bytes per entry), then each ladder step gathers the coordinates
 //                   of the entry its digit selects (wavefront-level gather, one entry per lane) a whole
-//                   doubling ahead of their use.
+//                   doubling ahead of their use.  Large batches build the tables in a kernel of their own into
+//                   packed 128-byte entries (two memory sectors per gather) and ladder at four waves per SIMD.
 //   fixed base    : the 8-entry table is staged once per workgroup into LDS (padded to dodge bank
 //                   conflicts) and gathered from there.
 //   selection     : the sign of a digit is applied branch-free (address choice for the N/D swap, a two-op
 //                   conditional negation for F); the table index is a per-lane address, as in the reference
-//                   (curve4q.py:232, :440).
+//                   (curve4q.py:232, :440).  With FOURQ_CT_SELECT / fourq_ctx_set_ct_select every step reads the
+//                   whole table instead and selects by masks (fourq_ct_*.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

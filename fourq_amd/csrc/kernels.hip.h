@@ -1,7 +1,10 @@
 // Shared device code of libfourq_amd.so: ladder arguments, table construction, the ladders and the kernels
-// built from them.  Included by two translation units that differ only in FQ_CHAIN (fp127.hip.h):
-//   fourq_amd.hip    FQ_CHAIN=0  fused variable-base kernels (table + ladder in one launch), primitives, C ABI
-//   fourq_chain.hip  FQ_CHAIN=1  fixed-base (LDS), two-kernel route (prep + PREBUILT ladder), comb
+// built from them.  Included by four translation units; the first two differ only in FQ_CHAIN (fp127.hip.h), the last
+// two are their builds with constant-time table selection (ladder_kernel<..., CT = true>):
+//   fourq_amd.hip       FQ_CHAIN=0  fused variable-base kernels (table + ladder in one launch), primitives, C ABI
+//   fourq_chain.hip     FQ_CHAIN=1  fixed-base (LDS), two-kernel route (prep + PREBUILT ladder), comb
+//   fourq_ct_fused.hip  FQ_CHAIN=0  fused kernels, the lane's table scanned in registers
+//   fourq_ct_chain.hip  FQ_CHAIN=1  fixed-base (LDS) ladders and comb, the whole table read at every step
 // Measured on MI355X (2^20 elements): chaining each column's carry into the next column's first multiply-add
 // gains 4-10 % for every kernel of the second group and costs the fused kernels 12-15 % when applied wholesale;
 // the fused kernels therefore use it only in their ladders, with preloaded table entries (see below).
