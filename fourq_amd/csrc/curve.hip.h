@@ -355,6 +355,13 @@ struct LimbSlots {
     template <typename P> static FQ_DEV Fe2<1> load(const P* src) { return load_fe2_limbs(src); }
     template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) { store_fe2_limbs(dst, v); }
 };
+// N and D only (the fused kernels keep E and F in LDS, kernels.hip.h LdsEF): 96-byte entries, each inside two sectors, and a
+// 1 088-byte slot: 8 192 lanes of an XCD then keep 6.3 MB of entries, of which its 4 MiB L2 holds most
+struct NDSlots {
+    static constexpr int COORD = COORD_U32, ENTRY = 2 * COORD_U32, PARK_P = 8 * 2 * COORD_U32, PARK_Q = 8 * 2 * COORD_U32 + 40, SLOT = 272;
+    template <typename P> static FQ_DEV Fe2<1> load(const P* src) { return load_fe2_limbs(src); }
+    template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) { store_fe2_limbs(dst, v); }
+};
 // tight limbs (after fe_carry) -> one 128-bit word: fold bits >= 127 (2^127 == 1), ripple once, concatenate
 FQ_DEV uint4 fe_pack128(const Fe<1>& a) {
     u32 l0 = a.l[0] + (a.l[4] >> 23), l1 = a.l[1], l2 = a.l[2], l3 = a.l[3], l4 = a.l[4] & 0x7fffff;
@@ -429,11 +436,16 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename L = LimbSlots, typename P> 
 struct EntryRegs {
     Fe2<1> N, D, E, F;
 };
-template <typename L = LimbSlots, typename P> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask) {
+// `ef` (kernels.hip.h: LdsEF / NoEF): where E and F come from -- the entry itself, or the lane's copy of them in LDS
+template <typename L = LimbSlots, typename P, typename EF> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask, u32 digit, const EF& ef) {
     const int off_n = neg_mask ? L::COORD : 0, off_d = neg_mask ? 0 : L::COORD;
     EntryRegs t;
     t.N = L::load(entry + off_n); t.D = L::load(entry + off_d);
-    t.E = L::load(entry + 2 * L::COORD); t.F = L::load(entry + 3 * L::COORD);
+    if constexpr (EF::ON) {
+        t.E = ef.get(digit, 0); t.F = ef.get(digit, 1);
+    } else {
+        t.E = L::load(entry + 2 * L::COORD); t.F = L::load(entry + 3 * L::COORD);
+    }
     return t;
 }
 template <int CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_mask) {

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const uint8_t* flags, 
 
 // One lane per table entry: P[j][u] = [2^(e j) (1 + u0 2^d + u1 2^2d + u2 2^3d + u3 2^4d)] B by the ordinary
 // variable-base MUL_endo, normalised to affine and stored as (x+y, y-x, 2d x y), 12 packed words.
-__global__ __launch_bounds__(128) void comb_table_kernel(const u64* p_r1, u32* scratch, u64* comb) {
+__global__ __launch_bounds__(COMB_POINTS) void comb_table_kernel(const u64* p_r1, u32* scratch, u64* comb) {
     const u32 t = threadIdx.x;
     if (t >= COMB_POINTS) return;
     const u32 j = t >> (COMB_W - 1), u = t & ((1u << (COMB_W - 1)) - 1);
@@ -332,8 +332,8 @@ struct fourq_ctx {
     u32* table_limbs = nullptr;    // 8 x 48: the staged fixed-base table as working limbs
     u32* table_slots = nullptr;    // the same in the PrebuiltSlots layout
     u64* table_packed = nullptr;   // 128 words
-    u32* comb_limbs = nullptr;     // 80 x 36 working limbs of the staged comb table
-    u64* comb_packed = nullptr;    // 80 x 12 words
+    u32* comb_limbs = nullptr;     // FOURQ_COMB_POINTS x 36 working limbs of the staged comb table
+    u64* comb_packed = nullptr;    // FOURQ_COMB_POINTS x 12 words
     uint64_t table_shadow[FOURQ_TABLE_WORDS];   // host copies of what table_limbs / comb_limbs currently hold
     uint64_t comb_shadow[FOURQ_COMB_WORDS];
     bool table_staged = false, comb_staged = false;
@@ -960,7 +960,7 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
     int rc = ensure_stage(c, 160);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->stage, p_r1, 160, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(comb_table_kernel, dim3(1), dim3(128), 0, c->stream, (const u64*)c->stage, c->scratch, c->comb_packed);
+    hipLaunchKernelGGL(comb_table_kernel, dim3(1), dim3(COMB_POINTS), 0, c->stream, (const u64*)c->stage, c->scratch, c->comb_packed);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(comb, c->comb_packed, FOURQ_COMB_WORDS * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -975,7 +975,7 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
         c->comb_staged = false;
         memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
         HIP_TRY(c, hipMemcpyAsync(c->comb_packed, c->comb_shadow, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(comb_unpack_kernel, dim3(1), dim3(128), 0, c->stream, c->comb_packed, c->comb_limbs);
+        hipLaunchKernelGGL(comb_unpack_kernel, dim3(1), dim3(COMB_POINTS), 0, c->stream, c->comb_packed, c->comb_limbs);
         HIP_TRY(c, hipGetLastError());
         c->comb_staged = true;
     }

@@ -46,6 +46,59 @@ typedef LimbSlots FusedSlots;
 constexpr int PROJ_PLANES = 8;            // deferred normalisation: the 30 working limbs of (X, Y, Z) in eight uint4 planes
 constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
 
+// A second copy of the E and F coordinates of the lane's eight entries in LDS (fused kernels, one wave per SIMD: 8 entries x
+// 2 coordinates x 40 bytes x 256 lanes = exactly the CU's 160 KiB).  A ladder step then gathers only N and D from the lane's
+// HBM slot -- bytes 0..95 of a 192-byte entry: two 64-byte sectors instead of three -- and reads E and F from LDS, with no
+// extra arithmetic.  Layout [entry][coordinate][limb pair][lane] x 8 bytes: a wave's 64 lanes hit 64 distinct bank pairs
+// whatever their digits are.
+#ifndef FQ_FUSED_LDS_EF
+#define FQ_FUSED_LDS_EF 1
+#endif
+constexpr int EF_LDS_U32 = 8 * 2 * 5 * 2 * 256;               // dwords: 163 840 bytes
+struct LdsEF {
+    static constexpr bool ON = true;
+    uint2* lane;                                               // the block's array + threadIdx.x
+    FQ_DEV void put1(int k, int c, const Fe2<1>& v) const {
+        uint2* q = lane + (size_t)((k * 2 + c) * 5) * 256;
+        q[0] = make_uint2(v.re.l[0], v.re.l[1]); q[256] = make_uint2(v.re.l[2], v.re.l[3]); q[512] = make_uint2(v.re.l[4], v.im.l[0]);
+        q[768] = make_uint2(v.im.l[1], v.im.l[2]); q[1024] = make_uint2(v.im.l[3], v.im.l[4]);
+    }
+    FQ_DEV void put(int k, const R2& t) const { put1(k, 0, t.E); put1(k, 1, t.F); }
+    FQ_DEV Fe2<1> get(u32 k, int c) const {
+        const uint2* q = lane + (size_t)((k * 2 + c) * 5) * 256;
+        const uint2 a = q[0], b = q[256], d = q[512], e = q[768], f = q[1024];
+        Fe2<1> r;
+        r.re.l[0] = a.x; r.re.l[1] = a.y; r.re.l[2] = b.x; r.re.l[3] = b.y; r.re.l[4] = d.x;
+        r.im.l[0] = d.y; r.im.l[1] = e.x; r.im.l[2] = e.y; r.im.l[3] = f.x; r.im.l[4] = f.y;
+        return r;
+    }
+};
+struct NoEF {
+    static constexpr bool ON = false;
+    FQ_DEV void put(int, const R2&) const {}
+    FQ_DEV Fe2<1> get(u32, int) const { return Fe2<1>{}; }
+};
+
+// entry k of a lane's table: with an LdsEF only N and D go to (come from) the HBM slot, E and F live in LDS alone
+template <typename L, typename EF> FQ_DEV void store_entry(u32* slot, int k, const R2& t, const EF& ef) {
+    if constexpr (EF::ON) {
+        L::store(slot + k * L::ENTRY, t.N); L::store(slot + k * L::ENTRY + L::COORD, t.D);
+        ef.put(k, t);
+    } else {
+        store_r2<L>(slot + k * L::ENTRY, t);
+    }
+}
+template <typename L, typename EF> FQ_DEV R2 load_entry_r2(const u32* slot, int k, const EF& ef) {
+    if constexpr (EF::ON) {
+        R2 t;
+        t.N = L::load(slot + k * L::ENTRY); t.D = L::load(slot + k * L::ENTRY + L::COORD);
+        t.E = ef.get((u32)k, 0); t.F = ef.get((u32)k, 1);
+        return t;
+    } else {
+        return load_r2<L>(slot + k * L::ENTRY);
+    }
+}
+
 enum Algo { ENDO = 0, WINDOWED = 1 };
 // where the ladder finds its table:
 //   FUSED     built by the same lane into its scratch slot just before the ladder (small batches: one launch)
@@ -119,14 +172,14 @@ FQ_DEV void load_proj_xy(const uint4* proj, u32 stride, u32 id, Fe2<1>& X, Fe2<1
 }
 
 // T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                       curve4q.py:179-185
-template <typename L = LimbSlots> FQ_DEV void build_table_windowed(const R1& P, u32* tbl) {
+template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_windowed(const R1& P, u32* tbl, const EF& ef = EF()) {
     R3 twoP = r1_to_r3(dbl(P));
     R2 t = r1_to_r2(P);
-    store_r2<L>(tbl, t);
+    store_entry<L>(tbl, 0, t, ef);
 #pragma unroll 1
     for (int i = 1; i < 8; i++) {
         t = r1_to_r2(add_core(twoP, as_signed(t)));
-        store_r2<L>(tbl + i * L::ENTRY, t);
+        store_entry<L>(tbl, i, t, ef);
     }
 }
 
@@ -201,15 +254,17 @@ template <int CH> FQ_DEV R1 ladder_result(const R1& Q) {
         return Q;
     }
 }
-template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride) {   // curve4q.py:436-442
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:436-442
     Proj<1, 1, 1> q4 = start_table<L>(tbl + (e.top & 7) * stride, 0u);        // s[64] = 1: the entry itself
+    if constexpr (EF::ON) q4.Z = ef.get(e.top & 7, 0);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
-        const TP* entry = tbl + endo_digit(e, i) * stride;
+        const u32 digit = endo_digit(e, i);
+        const TP* entry = tbl + digit * stride;
         if (PRELOAD) {
             const u32 neg = endo_neg_mask(e, i);
-            EntryRegs t = load_entry<L>(entry, neg);
+            EntryRegs t = load_entry<L>(entry, neg, digit, ef);
             Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_entry<CH>(Q, t, neg);
         } else {
@@ -219,9 +274,10 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
     }
     return ladder_result<CH>(Q);
 }
-template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride) {   // curve4q.py:228-235
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
     Proj<1, 1, 1> q4 = start_table<L>(tbl + (code & 7) * stride, (code >> 3) - 1u);
+    if constexpr (EF::ON) q4.Z = ef.get(code & 7, 0);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
@@ -229,7 +285,7 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
         const TP* entry = tbl + (code & 7) * stride;
         const u32 neg = (code >> 3) - 1u;
         if (PRELOAD) {
-            EntryRegs t = load_entry<L>(entry, neg);
+            EntryRegs t = load_entry<L>(entry, neg, code & 7, ef);
 #pragma unroll 1
             for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_entry<CH>(Q, t, neg);
@@ -280,7 +336,7 @@ FQ_DEV void memory_point() {
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0); expcnt and lgkmcnt untouched
     __builtin_amdgcn_sched_barrier(0);
 }
-template <typename L = LimbSlots> FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot) {
+template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot, const EF& ef = EF()) {
     constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
     R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
     int result_at = 0;
@@ -288,7 +344,7 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo_lone_wave(const R
 #pragma unroll 1
     for (int step = 0; step < 3; step++) {
         memory_point();                        // X, Y, Z (requested during the previous additions) are here
-        store_r2<L>(slot + result_at * L::ENTRY, result);
+        store_entry<L>(slot, result_at, result, ef);
         __builtin_amdgcn_sched_barrier(0);
         Proj<1, 2, 1> t;
         if (step == 1) {                       // phi and psi share tau(P), curve4q.py:318-322
@@ -305,7 +361,7 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo_lone_wave(const R
             u.X = widen<2>(c.X); u.Y = widen<2>(c.Y); u.Z = widen<2>(c.Z);
         }
         memory_point();                        // request T[0] one isogeny before the first addition
-        R2 base = load_r2<L>(slot);
+        R2 base = load_entry_r2<L>(slot, 0, ef);
         __builtin_amdgcn_sched_barrier(0);
         R1 V = tau_dual(u.X, u.Y, u.Z);
         R3 V3 = r1_to_r3(V);
@@ -313,9 +369,9 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo_lone_wave(const R
 #pragma unroll 1
         for (int m = 0; m < half; m++) {
             memory_point();                    // `base` is here; whatever was stored last is acknowledged
-            if (m > 0) store_r2<L>(slot + result_at * L::ENTRY, result);
+            if (m > 0) store_entry<L>(slot, result_at, result, ef);
             R2 next = base;
-            if (m + 1 < half) next = load_r2<L>(slot + (m + 1) * L::ENTRY);
+            if (m + 1 < half) next = load_entry_r2<L>(slot, m + 1, ef);
             if (m == 0 && step == 0) store_xyz(slot + SLOT_Q, V.X, V.Y, V.Z);
             if (m == half - 1 && step < 2) load_xyz(slot + (step == 0 ? SLOT_P : SLOT_Q), X, Y, Z);   // for the next step
             __builtin_amdgcn_sched_barrier(0);
@@ -324,7 +380,7 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo_lone_wave(const R
             base = next;
         }
     }
-    store_r2<L>(slot + result_at * L::ENTRY, result);     // T[7]; the ladder's first gather waits for it
+    store_entry<L>(slot, result_at, result, ef);     // T[7]; the ladder's first gather waits for it
 }
 
 // Experiment (FQ_TABLE_INTERLEAVE=1): the same table as straight-line code with the independent parts side by side --
@@ -398,7 +454,11 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
 template <int ALGO, int SRC, bool DH, bool DEFER = false, bool CT = false>
 __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
     static_assert(!DEFER || DH, "only DH outputs are normalised");
-    __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : 4];
+    constexpr bool USE_EF = SRC == FUSED && !CT && FQ_FUSED_LDS_EF && FQ_FUSED_PRELOAD;     // LdsEF: the CU's whole LDS for one block
+    __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : (USE_EF ? EF_LDS_U32 : 4)];
+    using EF = typename std::conditional<USE_EF, LdsEF, NoEF>::type;
+    EF ef;
+    if constexpr (USE_EF) ef.lane = reinterpret_cast<uint2*>(lds_table) + threadIdx.x;
     if (SRC == LDS) {
         for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
             lds_table[(i / R2_LIMBS) * LDS_ENTRY_U32 + (i % R2_LIMBS)] = a.table[i];
@@ -415,7 +475,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
-        using L = typename std::conditional<SRC == PREBUILT, PrebuiltSlots, FusedSlots>::type;
+        using L = typename std::conditional<SRC == PREBUILT, PrebuiltSlots, typename std::conditional<USE_EF, NDSlots, FusedSlots>::type>::type;
         u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * L::SLOT;
         const u32* tbl = slot;
         if (SRC == PREBUILT && a.slot_of) {                              // mixed batch: own table or the shared one
@@ -437,9 +497,9 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             }
             if (SRC == FUSED) {
                 if (ALGO == ENDO) {
-                    if (FQ_TABLE_INTERLEAVE) build_table_endo_interleaved<L>(P, slot); else build_table_endo_lone_wave<L>(P, slot);
+                    if (FQ_TABLE_INTERLEAVE) build_table_endo_interleaved<L>(P, slot); else build_table_endo_lone_wave<L>(P, slot, ef);
                 } else {
-                    build_table_windowed<L>(P, slot);
+                    build_table_windowed<L>(P, slot, ef);
                 }
             }
         }
@@ -457,7 +517,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
                 static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
                 Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else
-            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(e, tbl, L::ENTRY);
+            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(e, tbl, L::ENTRY, ef);
         } else {
             WinScalar w = win_reduce(m);
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
@@ -469,7 +529,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
                 static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
                 Q = ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else
-            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(w, tbl, L::ENTRY);
+            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(w, tbl, L::ENTRY, ef);
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
             if (live) {
@@ -503,12 +563,13 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 }
 
 // ---- fixed-base comb -------------------------------------------------------------
-constexpr int COMB_POINTS = COMB_V << (COMB_W - 1);          // 80
+constexpr int COMB_POINTS = COMB_V << (COMB_W - 1);          // 256
+static_assert(COMB_POINTS == FOURQ_COMB_POINTS, "include/fourq_amd.h and recode.hip.h disagree on the comb's shape");
 constexpr int COMB_ENTRY_U32 = 3 * COORD_U32;                 // (x+y, y-x, 2dxy)
-constexpr int COMB_LDS_U32 = COMB_ENTRY_U32 + 4;              // padded stride in LDS (0, 4, 8, 12 measured alike)
+constexpr int COMB_LDS_U32 = COMB_ENTRY_U32;                  // stride in LDS (pads of 0, 4, 8, 12 dwords measured alike); 36 KB per block
 
 #if FQ_CHAIN   // only fourq_chain.hip launches it
-// [m]B, affine, from the comb: 9 doublings + 49 mixed additions per element
+// [m]B, affine, from the comb: 8 doublings + 35 mixed additions per element
 constexpr int COMB_MODE = FQ_SIGNED_LADDER ? 2 : 1;          // the comb's additions run on signed limbs like the LDS ladders
 template <bool DEFER, bool CT = false>
 __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {

@@ -158,12 +158,16 @@ FQ_DEV u32 win_top_code(const WinScalar& w) {        // digit 62 = (r >> 252) | 
     return (1u << 3) | (((d - 1) >> 1) & 7);
 }
 
-// ---- fixed-base comb: mLSB-set recoding, w = 5, v = 5, e = 10, d = 50 -----------------
+// ---- fixed-base comb: mLSB-set recoding, w = 7, v = 4, e = 9, d = 36 ------------------
+// Shape chosen by the multiply-add count (e - 1) * 500 + (v * e - 1) * 700 under the LDS budget of four blocks per CU
+// (v * 2^(w-1) points of 144 bytes): (7, 4) = 8 doublings + 35 mixed additions = 28 500, 256 points; round 1's (5, 5) =
+// 9 + 49 = 38 800 with 80 points; (6, 5) 34 800; (8, 2) 29 200; anything cheaper needs more than 300 points.
 // (Faz-Hernandez, Longa, Sanchez: the method the draft points to for multiplications by the generator,
 // draft-ladd-cfrg-4q.md:725-729.)  For odd k < 2^250:  k = sum_{i<250} b_i 2^i with b_i in {+-1} for i < d and
-// b_i in {0, b_{i mod d}} above.  Column i (0 <= i < d) carries the sign b_i and the 4-bit index
-// (|b_{4d+i}| |b_{3d+i}| |b_{2d+i}| |b_{d+i}|); stored as five 50-bit planes.
-constexpr int COMB_W = 5, COMB_V = 5, COMB_E = 10, COMB_D = 50;
+// b_i in {0, b_{i mod d}} above.  Column i (0 <= i < d) carries the sign b_i and the (w-1)-bit index
+// (|b_{(w-1)d+i}| ... |b_{2d+i}| |b_{d+i}|); stored as w planes of d bits.
+constexpr int COMB_W = 7, COMB_V = 4, COMB_E = 9, COMB_D = 36;
+static_assert(COMB_V * COMB_E == COMB_D && COMB_W * COMB_D >= 250 && COMB_D <= 64, "comb shape");
 struct CombDigits {
     u64 plane[COMB_W];   // plane[0] bit i: b_i == +1 ; plane[r] bit i: |b_{r d + i}|
     u32 negate;          // ~0 when the scalar was replaced by N - k (even k): the result is negated
@@ -214,9 +218,11 @@ FQ_DEV CombDigits comb_recode(const u64 m[4]) {
     }
     return c;
 }
-FQ_DEV u32 comb_index(const CombDigits& c, int col) {    // 4-bit table index of column `col` (wave-uniform col)
-    return (u32)((c.plane[1] >> col) & 1) | ((u32)((c.plane[2] >> col) & 1) << 1) | ((u32)((c.plane[3] >> col) & 1) << 2) |
-           ((u32)((c.plane[4] >> col) & 1) << 3);
+FQ_DEV u32 comb_index(const CombDigits& c, int col) {    // (w-1)-bit table index of column `col` (wave-uniform col)
+    u32 idx = 0;
+#pragma unroll
+    for (int r = 1; r < COMB_W; r++) idx |= (u32)((c.plane[r] >> col) & 1) << (r - 1);
+    return idx;
 }
 FQ_DEV u32 comb_neg_mask(const CombDigits& c, int col) { return (u32)((c.plane[0] >> col) & 1) - 1u; }
 

@@ -226,13 +226,13 @@ class Engine:
         t = None if table392_host is None else _host(table392_host, None).ravel()
         self._ck(self._lib.fourq_dh_exchange_batch_dev(self._ctx, _ptr(a_scalars), _ptr(b_scalars), _ptr(base), _ptr(t), _ptr(out_affine), _ptr(status), n))
 
-    # ---- fixed-base comb (80-point table; affine outputs only) ------------------------------------
+    # ---- fixed-base comb (256-point table; affine outputs only) -----------------------------------
     def comb_table(self, p_r1):
-        """960-word comb table of the order-N point `p_r1` (fourq_comb_table)."""
+        """Comb table (_lib.COMB_WORDS words) of the order-N point `p_r1` (fourq_comb_table)."""
         p = _host(p_r1, None).ravel()
         if p.size != 20:
             raise ValueError("an R1 point is 20 words")
-        out = np.empty(960, dtype=np.uint64)
+        out = np.empty(_lib.COMB_WORDS, dtype=np.uint64)
         self._ck(self._lib.fourq_comb_table(self._ctx, _ptr(p), _ptr(out)))
         return out
 
@@ -240,8 +240,8 @@ class Engine:
         """Affine [m_i]B for the comb's base B: ((n, 8) words, status) -- equals R1toAffine(MUL_endo(m_i, B))."""
         s = _host(scalars, 4)
         t = _host(comb, None).ravel()
-        if t.size != 960:
-            raise ValueError("a comb table is 960 words")
+        if t.size != _lib.COMB_WORDS:
+            raise ValueError("a comb table is %d words" % _lib.COMB_WORDS)
         out = np.empty((len(s), 8), dtype=np.uint64)
         status = np.empty(len(s), dtype=np.uint8)
         self._ck(self._lib.fourq_comb_mul_batch(self._ctx, _ptr(s), _ptr(t), _ptr(out), _ptr(status), len(s)))
@@ -249,6 +249,8 @@ class Engine:
 
     def comb_mul_dev(self, scalars, comb_host, out_affine, status, n):
         t = _host(comb_host, None).ravel()
+        if t.size != _lib.COMB_WORDS:
+            raise ValueError("a comb table is %d words" % _lib.COMB_WORDS)
         self._ck(self._lib.fourq_comb_mul_batch_dev(self._ctx, _ptr(scalars), _ptr(t), _ptr(out_affine), _ptr(status), n))
 
     # ---- point compression (32-byte wire format) -------------------------------------------------
