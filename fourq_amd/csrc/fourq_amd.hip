@@ -109,16 +109,13 @@ __global__ __launch_bounds__(BLOCK) void partition_kernel(const uint8_t* flags, 
     }
 }
 
-// One lane per table entry: P[j][u] = [2^(e j) (1 + u0 2^d + u1 2^2d + u2 2^3d + u3 2^4d)] B by the ordinary
+// One lane per point of the table object (both shapes, recode.hip.h): [2^(e j) (1 + u0 2^d + u1 2^2d + ...)] B by the ordinary
 // variable-base MUL_endo, normalised to affine and stored as (x+y, y-x, 2d x y), 12 packed words.
-__global__ __launch_bounds__(COMB_POINTS) void comb_table_kernel(const u64* p_r1, u32* scratch, u64* comb) {
-    const u32 t = threadIdx.x;
-    if (t >= COMB_POINTS) return;
-    const u32 j = t >> (COMB_W - 1), u = t & ((1u << (COMB_W - 1)) - 1);
-    u64 m[4] = { 0, 0, 0, 0 };
-    auto set_bit = [&](int bit) { m[bit >> 6] |= 1ull << (bit & 63); };
-    set_bit(COMB_E * j);
-    for (int r = 0; r < COMB_W - 1; r++) if ((u >> r) & 1) set_bit(COMB_E * j + (r + 1) * COMB_D);
+__global__ __launch_bounds__(BLOCK) void comb_table_kernel(const u64* p_r1, u32* scratch, u64* comb) {
+    const u32 t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (u32)COMB_POINTS) return;
+    u64 m[4];
+    if (t < (u32)CombFast::POINTS) comb_point_scalar<CombFast>(t, m); else comb_point_scalar<CombScan>(t - CombFast::POINTS, m);
     R1 P = load_r1(p_r1);
     u32* slot = scratch + (size_t)t * SLOT_U32;
     build_table_endo(P, slot);
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(COMB_POINTS) void comb_table_kernel(const u64* p_r1
     store_fe2(dst + 8, fe2_mul(fe2_mul(x, y), fe2_two_d()));
 }
 __global__ void comb_unpack_kernel(const u64* packed, u32* limbs) {
-    int k = threadIdx.x;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= COMB_POINTS) return;
     for (int c = 0; c < 3; c++) store_fe2_limbs(limbs + k * COMB_ENTRY_U32 + c * COORD_U32, load_fe2(packed + 12 * k + 4 * c));
 }
@@ -960,7 +957,7 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
     int rc = ensure_stage(c, 160);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->stage, p_r1, 160, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(comb_table_kernel, dim3(1), dim3(COMB_POINTS), 0, c->stream, (const u64*)c->stage, c->scratch, c->comb_packed);
+    hipLaunchKernelGGL(comb_table_kernel, dim3((COMB_POINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, (const u64*)c->stage, c->scratch, c->comb_packed);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(comb, c->comb_packed, FOURQ_COMB_WORDS * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -975,7 +972,7 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
         c->comb_staged = false;
         memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
         HIP_TRY(c, hipMemcpyAsync(c->comb_packed, c->comb_shadow, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(comb_unpack_kernel, dim3(1), dim3(COMB_POINTS), 0, c->stream, c->comb_packed, c->comb_limbs);
+        hipLaunchKernelGGL(comb_unpack_kernel, dim3((COMB_POINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->comb_packed, c->comb_limbs);
         HIP_TRY(c, hipGetLastError());
         c->comb_staged = true;
     }

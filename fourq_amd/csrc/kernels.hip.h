@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 }
 
 // ---- fixed-base comb -------------------------------------------------------------
-constexpr int COMB_POINTS = COMB_V << (COMB_W - 1);          // 256
+constexpr int COMB_POINTS = COMB_POINTS_ALL;                  // 256 (by address) + 80 (constant-time mode)
 static_assert(COMB_POINTS == FOURQ_COMB_POINTS, "include/fourq_amd.h and recode.hip.h disagree on the comb's shape");
 constexpr int COMB_ENTRY_U32 = 3 * COORD_U32;                 // (x+y, y-x, 2dxy)
 constexpr int COMB_LDS_U32 = COMB_ENTRY_U32;                  // stride in LDS (pads of 0, 4, 8, 12 dwords measured alike); 36 KB per block
@@ -573,9 +573,11 @@ constexpr int COMB_LDS_U32 = COMB_ENTRY_U32;                  // stride in LDS (
 constexpr int COMB_MODE = FQ_SIGNED_LADDER ? 2 : 1;          // the comb's additions run on signed limbs like the LDS ladders
 template <bool DEFER, bool CT = false>
 __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
-    __shared__ __attribute__((aligned(16))) u32 lds[COMB_POINTS * COMB_LDS_U32];
-    for (int i = threadIdx.x; i < COMB_POINTS * COMB_ENTRY_U32; i += BLOCK)
-        lds[(i / COMB_ENTRY_U32) * COMB_LDS_U32 + (i % COMB_ENTRY_U32)] = comb_limbs[i];
+    using S = typename std::conditional<CT, CombScan, CombFast>::type;       // the constant-time mode scans the small sub-table
+    __shared__ __attribute__((aligned(16))) u32 lds[S::POINTS * COMB_LDS_U32];
+    const u32* sub = comb_limbs + (CT ? CombFast::POINTS * COMB_ENTRY_U32 : 0);
+    for (int i = threadIdx.x; i < S::POINTS * COMB_ENTRY_U32; i += BLOCK)
+        lds[(i / COMB_ENTRY_U32) * COMB_LDS_U32 + (i % COMB_ENTRY_U32)] = sub[i];
     __syncthreads();
     const u32 lanes = gridDim.x * BLOCK;
     const u32 n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
@@ -585,22 +587,22 @@ __global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, cons
         const u32 id = live ? it : n - 1;
         u64 m[4];
         load_scalar(scalars + 4 * (size_t)id, m);
-        CombDigits c = comb_recode(m);
+        CombDigits<S> c = comb_recode<S>(m);
         R1 Q;
 #pragma unroll 1
-        for (int i = COMB_E - 1; i >= 0; i--) {
+        for (int i = S::E - 1; i >= 0; i--) {
 #pragma unroll 1
-            for (int j = 0; j < COMB_V; j++) {
-                const int col = COMB_E * j + i;
+            for (int j = 0; j < S::V; j++) {
+                const int col = S::E * j + i;
                 const u32 neg = comb_neg_mask(c, col);
-                if constexpr (CT) {                      // all 16 entries of block j are read; the index only forms masks
-                    const ScanMem<1 << (COMB_W - 1), u32> block{ lds + (j << (COMB_W - 1)) * COMB_LDS_U32, COMB_LDS_U32 };
-                    if (i == COMB_E - 1 && j == 0) { Q = affine_scan_start(block, comb_index(c, col), neg); continue; }
+                if constexpr (CT) {                      // all entries of block j are read; the index only forms masks
+                    const ScanMem<S::BLOCK_POINTS, u32> block{ lds + (j << (S::W - 1)) * COMB_LDS_U32, COMB_LDS_U32 };
+                    if (i == S::E - 1 && j == 0) { Q = affine_scan_start(block, comb_index(c, col), neg); continue; }
                     if (j == 0) Q = dbl<COMB_MODE>(Q.X, Q.Y, Q.Z);
                     Q = add_affine_scan<COMB_MODE>(Q, block, comb_index(c, col), neg);
                 } else {
-                    const u32* entry = lds + ((j << (COMB_W - 1)) + comb_index(c, col)) * COMB_LDS_U32;
-                    if (i == COMB_E - 1 && j == 0) { Q = affine_table_start(entry, neg); continue; }
+                    const u32* entry = lds + ((j << (S::W - 1)) + comb_index(c, col)) * COMB_LDS_U32;
+                    if (i == S::E - 1 && j == 0) { Q = affine_table_start(entry, neg); continue; }
                     if (j == 0) Q = dbl<COMB_MODE>(Q.X, Q.Y, Q.Z);
                     Q = add_affine_table<COMB_MODE>(Q, entry, neg);
                 }

@@ -158,7 +158,7 @@ FQ_DEV u32 win_top_code(const WinScalar& w) {        // digit 62 = (r >> 252) | 
     return (1u << 3) | (((d - 1) >> 1) & 7);
 }
 
-// ---- fixed-base comb: mLSB-set recoding, w = 7, v = 4, e = 9, d = 36 ------------------
+// ---- fixed-base comb: mLSB-set recoding, w = 7, v = 4, e = 9, d = 36 (and 5, 5, 10, 50) --
 // Shape chosen by the multiply-add count (e - 1) * 500 + (v * e - 1) * 700 under the LDS budget of four blocks per CU
 // (v * 2^(w-1) points of 144 bytes): (7, 4) = 8 doublings + 35 mixed additions = 28 500, 256 points; round 1's (5, 5) =
 // 9 + 49 = 38 800 with 80 points; (6, 5) 34 800; (8, 2) 29 200; anything cheaper needs more than 300 points.
@@ -166,13 +166,21 @@ FQ_DEV u32 win_top_code(const WinScalar& w) {        // digit 62 = (r >> 252) | 
 // draft-ladd-cfrg-4q.md:725-729.)  For odd k < 2^250:  k = sum_{i<250} b_i 2^i with b_i in {+-1} for i < d and
 // b_i in {0, b_{i mod d}} above.  Column i (0 <= i < d) carries the sign b_i and the (w-1)-bit index
 // (|b_{(w-1)d+i}| ... |b_{2d+i}| |b_{d+i}|); stored as w planes of d bits.
-constexpr int COMB_W = 7, COMB_V = 4, COMB_E = 9, COMB_D = 36;
-static_assert(COMB_V * COMB_E == COMB_D && COMB_W * COMB_D >= 250 && COMB_D <= 64, "comb shape");
-struct CombDigits {
-    u64 plane[COMB_W];   // plane[0] bit i: b_i == +1 ; plane[r] bit i: |b_{r d + i}|
+// Two shapes share one table object: the fast one for selection by address and a small one for the constant-time mode, whose
+// additions read a whole block of 2^(w-1) entries (35 scans of 64 entries cost more than 49 scans of 16: DESIGN.md section 10).
+template <int W_, int V_, int E_> struct CombShape {
+    static constexpr int W = W_, V = V_, E = E_, D = V_ * E_, BLOCK_POINTS = 1 << (W_ - 1), POINTS = V_ << (W_ - 1);
+    static_assert(W_ * V_ * E_ >= 250 && V_ * E_ <= 64, "comb shape");
+};
+typedef CombShape<7, 4, 9> CombFast;       // 256 points: 8 doublings + 35 mixed additions
+typedef CombShape<5, 5, 10> CombScan;      // 80 points: 9 doublings + 49 mixed additions, 16-entry blocks
+constexpr int COMB_POINTS_ALL = CombFast::POINTS + CombScan::POINTS;       // the table object: fast points first
+template <typename S> struct CombDigits {
+    u64 plane[S::W];     // plane[0] bit i: b_i == +1 ; plane[r] bit i: |b_{r d + i}|
     u32 negate;          // ~0 when the scalar was replaced by N - k (even k): the result is negated
 };
-FQ_DEV CombDigits comb_recode(const u64 m[4]) {
+template <typename S> FQ_DEV CombDigits<S> comb_recode(const u64 m[4]) {
+    constexpr int COMB_W = S::W, COMB_D = S::D;
     WinScalar red = win_reduce(m);                    // k mod N made odd by ADDING N when even (curve4q.py:217-219) ...
     // ... the comb wants odd k < N instead: undo the +N and use N - k, negating the result
     u64 k[4] = { red.r[0], red.r[1], red.r[2], red.r[3] };
@@ -190,14 +198,14 @@ FQ_DEV CombDigits comb_recode(const u64 m[4]) {
         u64 d2 = d1 - borrow, b2 = d1 < borrow;
         alt[i] = d2; borrow = b1 | b2;
     }
-    CombDigits c;
+    CombDigits<S> c;
     c.negate = was_even ? ~0u : 0u;
 #pragma unroll
     for (int i = 0; i < 4; i++) k[i] = was_even ? alt[i] : k[i];        // odd, in [1, N]
     const u64 mask_d = (1ull << COMB_D) - 1;
     const u64 sign = ((k[0] >> 1) & (mask_d >> 1)) | (1ull << (COMB_D - 1));     // b_i = +1  <=>  bit set
     c.plane[0] = sign;
-    // carry word c = k >> d (200 bits)
+    // carry word c = k >> d
     u64 c0 = (k[0] >> COMB_D) | (k[1] << (64 - COMB_D)), c1 = (k[1] >> COMB_D) | (k[2] << (64 - COMB_D));
     u64 c2 = (k[2] >> COMB_D) | (k[3] << (64 - COMB_D)), c3 = k[3] >> COMB_D;
 #pragma unroll 1
@@ -218,12 +226,20 @@ FQ_DEV CombDigits comb_recode(const u64 m[4]) {
     }
     return c;
 }
-FQ_DEV u32 comb_index(const CombDigits& c, int col) {    // (w-1)-bit table index of column `col` (wave-uniform col)
+template <typename S> FQ_DEV u32 comb_index(const CombDigits<S>& c, int col) {    // (w-1)-bit table index of column `col` (wave-uniform col)
     u32 idx = 0;
 #pragma unroll
-    for (int r = 1; r < COMB_W; r++) idx |= (u32)((c.plane[r] >> col) & 1) << (r - 1);
+    for (int r = 1; r < S::W; r++) idx |= (u32)((c.plane[r] >> col) & 1) << (r - 1);
     return idx;
 }
-FQ_DEV u32 comb_neg_mask(const CombDigits& c, int col) { return (u32)((c.plane[0] >> col) & 1) - 1u; }
+template <typename S> FQ_DEV u32 comb_neg_mask(const CombDigits<S>& c, int col) { return (u32)((c.plane[0] >> col) & 1) - 1u; }
+// point t of shape S's sub-table: [2^(e j) (1 + u0 2^d + u1 2^2d + ...)] B for t = (j, u); the scalar as 256 bits
+template <typename S> FQ_DEV void comb_point_scalar(u32 t, u64 m[4]) {
+    const u32 j = t >> (S::W - 1), u = t & ((1u << (S::W - 1)) - 1);
+    m[0] = m[1] = m[2] = m[3] = 0;
+    auto set_bit = [&](int bit) { m[bit >> 6] |= 1ull << (bit & 63); };
+    set_bit(S::E * j);
+    for (int r = 0; r < S::W - 1; r++) if ((u >> r) & 1) set_bit(S::E * j + (r + 1) * S::D);
+}
 
 }  // namespace fq

@@ -1,4 +1,5 @@
-"""Fixed-base comb: affine [m]B from a 256-point table (w = 7, v = 4, e = 9, d = 36).  Parity is at the affine level
+"""Fixed-base comb: affine [m]B from a 256-point table (w = 7, v = 4, e = 9, d = 36; the constant-time mode scans
+an 80-point comb, w = v = 5, kept in the same table object).  Parity is at the affine level
 (the draft's "MAY use any method ... provided that it agrees", draft-ladd-cfrg-4q.md:725-729): outputs must
 equal R1toAffine(MUL_endo(m, B)) and, for B = [392]G, DH_endo(m, G)."""
 import random
@@ -21,10 +22,11 @@ def seeded_scalars(seed, n):
 
 
 def test_comb_table_entries(eng):
-    W, V, E, D = 7, 4, 9, 36
-    comb = eng.comb_table(codec.pack_point(G1)).reshape(V << (W - 1), 12)
-    for t in (0, 1, 63, 64, 101, 191, 255):
-        j, u = t >> (W - 1), t & ((1 << (W - 1)) - 1)
+    from fourq_amd import _lib
+    comb = eng.comb_table(codec.pack_point(G1)).reshape(_lib.COMB_POINTS, 12)
+    for t in (0, 1, 63, 64, 101, 191, 255, 256, 257, 272, 300, 335):       # both shapes of the table object
+        (W, V, E, D), s = ((7, 4, 9, 36), t) if t < 256 else ((5, 5, 10, 50), t - 256)
+        j, u = s >> (W - 1), s & ((1 << (W - 1)) - 1)
         m = (1 << (E * j)) * (1 + sum(((u >> r) & 1) << (D * (r + 1)) for r in range(W - 1)))
         x, y = o.R1toAffine(o.MUL_endo(m % o.N, G1))
         want = (o.f2_add(x, y), o.f2_sub(y, x), o.f2_mul(o.TWO_D, o.f2_mul(x, y)))
@@ -35,7 +37,7 @@ def test_comb_equals_mul_endo_affine(eng):
     rng = random.Random(77)
     B = o.MUL_endo(rng.getrandbits(256), G1)                    # a projective base point of order N
     comb = eng.comb_table(codec.pack_point(B))
-    ms = [0, 1, 2, 3, o.N - 1, o.N, o.N + 1, 2 * o.N, (1 << 256) - 1, 1 << 255, 1 << 36, (1 << 36) - 1, 1 << 216, (1 << 245) + 1] + [rng.getrandbits(256) for _ in range(40)]
+    ms = [0, 1, 2, 3, o.N - 1, o.N, o.N + 1, 2 * o.N, (1 << 256) - 1, 1 << 255, 1 << 36, (1 << 36) - 1, 1 << 50, (1 << 50) - 1, 1 << 216, (1 << 245) + 1] + [rng.getrandbits(256) for _ in range(40)]
     out, st = eng.comb_mul(codec.pack_scalars(ms), comb)
     for m, got, s in zip(ms, out, st):
         want = o.R1toAffine(o.MUL_endo(m, B))

@@ -244,3 +244,20 @@ def test_ct_select_from_the_environment(monkeypatch):
     monkeypatch.delenv("FOURQ_CT_SELECT")
     with Engine(0) as e:
         assert not e.ct_select
+
+
+def test_batches_beyond_the_abi_limit_are_refused(eng):
+    """n > FOURQ_MAX_BATCH (the kernels' 32-bit counters round n up to whole 256-lane blocks) is FOURQ_ERR_INVALID before
+    anything is read or launched; the context stays usable."""
+    import ctypes
+    from fourq_amd import _lib
+    lib = _lib.load()
+    s, pts = seeded_scalars(3, 16), torsion_points(eng, 4, 16)
+    out = np.empty((16, 20), dtype=np.uint64)
+    ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
+    for n in (_lib.MAX_BATCH + 1, (1 << 32) - 1, 1 << 40):
+        assert lib.fourq_mul_endo_batch(eng._ctx, ptr(s), ptr(pts), ptr(out), n) == _lib.ERR_INVALID
+        assert lib.fourq_mul_endo_batch_dev(eng._ctx, ptr(s), ptr(pts), ptr(out), n) == _lib.ERR_INVALID
+        st = np.empty(16, dtype=np.uint8)
+        assert lib.fourq_dh_endo_batch(eng._ctx, ptr(s), ptr(pts), None, ptr(out), ptr(st), n) == _lib.ERR_INVALID
+    assert np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
