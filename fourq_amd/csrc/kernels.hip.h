@@ -333,7 +333,9 @@ template <int CH, typename SRC> FQ_DEV R1 ladder_windowed_scan(const WinScalar& 
 // registers cost prep_kernel its second wave per SIMD, so prep_kernel keeps the plain version above.
 FQ_DEV void memory_point() {
     __builtin_amdgcn_sched_barrier(0);
+#ifndef FQ_DIAG_NO_MEMPOINT                    // diagnostic builds of tools/microbench/phases.hip only (results are then wrong)
     __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0); expcnt and lgkmcnt untouched
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot, const EF& ef = EF()) {
