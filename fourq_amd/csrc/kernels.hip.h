@@ -64,6 +64,12 @@ struct LdsEF {
         q[768] = make_uint2(v.im.l[1], v.im.l[2]); q[1024] = make_uint2(v.im.l[3], v.im.l[4]);
     }
     FQ_DEV void put(int k, const R2& t) const { put1(k, 0, t.E); put1(k, 1, t.F); }
+    // The ten rows of an entry whose E, F are not there yet are free storage: table_endo parks its working values in them
+    // (build_table_endo_lds) instead of making round trips through the HBM slot.
+    FQ_DEV void park_nd(int k, const Fe2<1>& n, const Fe2<1>& d) const { put1(k, 0, n); put1(k, 1, d); }
+    FQ_DEV void unpark_nd(int k, Fe2<1>& n, Fe2<1>& d) const { n = get((u32)k, 0); d = get((u32)k, 1); }
+    FQ_DEV void park_xyz(int k, const Fe2<1>& x, const Fe2<1>& y, const Fe2<1>& z) const { put1(k, 0, x); put1(k, 1, y); put1(k + 1, 0, z); }
+    FQ_DEV void unpark_xyz(int k, Fe2<1>& x, Fe2<1>& y, Fe2<1>& z) const { x = get((u32)k, 0); y = get((u32)k, 1); z = get((u32)k + 1, 0); }
     FQ_DEV Fe2<1> get(u32 k, int c) const {
         const uint2* q = lane + (size_t)((k * 2 + c) * 5) * 256;
         const uint2 a = q[0], b = q[256], d = q[512], e = q[768], f = q[1024];
@@ -77,6 +83,10 @@ struct NoEF {
     static constexpr bool ON = false;
     FQ_DEV void put(int, const R2&) const {}
     FQ_DEV Fe2<1> get(u32, int) const { return Fe2<1>{}; }
+    FQ_DEV void park_nd(int, const Fe2<1>&, const Fe2<1>&) const {}
+    FQ_DEV void unpark_nd(int, Fe2<1>&, Fe2<1>&) const {}
+    FQ_DEV void park_xyz(int, const Fe2<1>&, const Fe2<1>&, const Fe2<1>&) const {}
+    FQ_DEV void unpark_xyz(int, Fe2<1>&, Fe2<1>&, Fe2<1>&) const {}
 };
 
 // entry k of a lane's table: with an LdsEF only N and D go to (come from) the HBM slot, E and F live in LDS alone
@@ -385,6 +395,65 @@ template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_en
     store_entry<L>(slot, result_at, result, ef);     // T[7]; the ladder's first gather waits for it
 }
 
+// table_endo for the fused kernels that keep E, F in LDS (LdsEF): the same DAG and the same order as above, but nothing is
+// ever read back from the HBM slot.  The working points and the N, D of the entries that later additions need are parked in
+// the LDS rows of entries that do not exist yet (each entry owns 80 bytes per lane):
+//     tau(P)      entries 6, 7   step 0 -> read at the end of step 0
+//     Q = phi(P)  entries 4, 5   step 0 -> read at the end of step 1
+//     N, D of T[k], k = 1, 2, 3: entry 8 - k, written when T[k] is stored, read as the base of T[2 + k] / T[4 + k] before
+//                 that entry's own E, F arrive (an iteration loads its next base BEFORE it stores the previous result)
+// T[0]'s N, D stay in registers.  The HBM slot receives N, D of every entry, write-only; loads and stores share vmcnt on
+// gfx950, so a table phase without loads has nothing to wait for until the ladder's first gather.
+#ifndef FQ_TABLE_LDS_PARK
+#define FQ_TABLE_LDS_PARK 1
+#endif
+template <typename L, typename EF> FQ_DEV void build_table_endo_lds(const R1& P, u32* slot, const EF& ef) {
+    static_assert(EF::ON, "needs the LDS copy of E and F");
+    R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
+    int result_at = 0;
+    const Fe2<1> n0 = result.N, d0 = result.D;
+    Fe2<1> X = P.X, Y = P.Y, Z = P.Z;          // step 0: P; step 1: tau(P); step 2: phi(P)
+    auto store_result = [&]() {
+        store_entry<L>(slot, result_at, result, ef);
+        if (result_at >= 1 && result_at <= 3) ef.park_nd(8 - result_at, result.N, result.D);
+    };
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        store_result();
+        Proj<1, 2, 1> t;
+        if (step == 1) {                       // phi and psi share tau(P), curve4q.py:318-322
+            t.X = X; t.Y = widen<2>(Y); t.Z = Z;
+        } else {
+            t = tau(X, Y, Z);
+            if (step == 0) ef.park_xyz(6, t.X, fe2_carry(t.Y), t.Z);
+        }
+        Proj<2, 2, 2> u;
+        if (step == 0) {
+            u = upsilon(t);
+        } else {
+            Proj<1, 1, 1> c = chi(t);
+            u.X = widen<2>(c.X); u.Y = widen<2>(c.Y); u.Z = widen<2>(c.Z);
+        }
+        R1 V = tau_dual(u.X, u.Y, u.Z);
+        R3 V3 = r1_to_r3(V);
+        R2 base;
+        base.N = n0; base.D = d0; base.E = ef.get(0, 0); base.F = ef.get(0, 1);
+        const int half = 1 << step;
+#pragma unroll 1
+        for (int m = 0; m < half; m++) {
+            R2 next = base;
+            if (m + 1 < half) { ef.unpark_nd(8 - (m + 1), next.N, next.D); next.E = ef.get((u32)(m + 1), 0); next.F = ef.get((u32)(m + 1), 1); }
+            if (m > 0) store_result();
+            if (m == 0 && step == 0) ef.park_xyz(4, V.X, V.Y, V.Z);
+            if (m == half - 1 && step < 2) ef.unpark_xyz(step == 0 ? 6 : 4, X, Y, Z);   // for the next step
+            result = r1_to_r2(add_core(V3, as_signed(base)));
+            result_at = half + m;
+            base = next;
+        }
+    }
+    store_result();                            // T[7]
+}
+
 // Experiment (FQ_TABLE_INTERLEAVE=1): the same table as straight-line code with the independent parts side by side --
 // phi(P) beside psi(P) behind the shared tau(P); psi(phi(P)) beside the three additions that do not need it; the last four
 // additions together -- so that a lone wave always has a second dependency chain to issue from.  Same DAG, same entries.
@@ -499,7 +568,9 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             }
             if (SRC == FUSED) {
                 if (ALGO == ENDO) {
-                    if (FQ_TABLE_INTERLEAVE) build_table_endo_interleaved<L>(P, slot); else build_table_endo_lone_wave<L>(P, slot, ef);
+                    if constexpr (USE_EF && FQ_TABLE_LDS_PARK) build_table_endo_lds<L>(P, slot, ef);
+                    else if (FQ_TABLE_INTERLEAVE) build_table_endo_interleaved<L>(P, slot);
+                    else build_table_endo_lone_wave<L>(P, slot, ef);
                 } else {
                     build_table_windowed<L>(P, slot, ef);
                 }
