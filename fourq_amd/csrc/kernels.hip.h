@@ -407,6 +407,10 @@ template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_en
 #ifndef FQ_TABLE_LDS_PARK
 #define FQ_TABLE_LDS_PARK 1
 #endif
+// decompose + recode before table_endo in the fused MUL_endo / DH_endo kernels (the digits then live across the table phase)
+#ifndef FQ_RECODE_FIRST
+#define FQ_RECODE_FIRST 0
+#endif
 template <typename L, typename EF> FQ_DEV void build_table_endo_lds(const R1& P, u32* slot, const EF& ef) {
     static_assert(EF::ON, "needs the LDS copy of E and F");
     R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
@@ -555,6 +559,8 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         }
 
         uint8_t st = FOURQ_DH_OK;
+        constexpr bool RECODE_FIRST = FQ_RECODE_FIRST && SRC == FUSED && ALGO == ENDO && !CT;
+        EndoDigits e_early = {};
         if (SRC == PREBUILT) {
             if (DH) st = a.status[id];                                  // membership verdict of prep_kernel
         } else {
@@ -565,6 +571,11 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
                 if (SRC == FUSED) P = clear_cofactor_392(x, y);         // with a table the reference discards [392]P (curve4q.py:209)
             } else if (SRC == FUSED) {
                 P = load_r1(a.points + 20 * (size_t)id);
+            }
+            if constexpr (RECODE_FIRST) {             // integer work on the scalar while the point's HBM load is in flight
+                u64 v[4];
+                decompose(m, v);
+                e_early = recode(v);
             }
             if (SRC == FUSED) {
                 if (ALGO == ENDO) {
@@ -578,9 +589,14 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         }
         R1 Q;
         if (ALGO == ENDO) {
-            u64 v[4];
-            decompose(m, v);
-            EndoDigits e = recode(v);
+            EndoDigits e;
+            if constexpr (RECODE_FIRST) {
+                e = e_early;
+            } else {
+                u64 v[4];
+                decompose(m, v);
+                e = recode(v);
+            }
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
             if constexpr (CT && SRC == FUSED) {
                 ScanRegs<8, 4> regs;
