@@ -411,14 +411,16 @@ template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_en
 #ifndef FQ_RECODE_FIRST
 #define FQ_RECODE_FIRST 0
 #endif
-template <typename L, typename EF> FQ_DEV void build_table_endo_lds(const R1& P, u32* slot, const EF& ef) {
+// FULL: the HBM slot receives whole entries (prep_kernel: another kernel gathers them later), not only N and D.
+template <typename L, typename EF, bool FULL = false> FQ_DEV void build_table_endo_lds(const R1& P, u32* slot, const EF& ef) {
     static_assert(EF::ON, "needs the LDS copy of E and F");
     R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
     int result_at = 0;
     const Fe2<1> n0 = result.N, d0 = result.D;
     Fe2<1> X = P.X, Y = P.Y, Z = P.Z;          // step 0: P; step 1: tau(P); step 2: phi(P)
     auto store_result = [&]() {
-        store_entry<L>(slot, result_at, result, ef);
+        if constexpr (FULL) { store_r2<L>(slot + result_at * L::ENTRY, result); ef.put(result_at, result); }
+        else store_entry<L>(slot, result_at, result, ef);
         if (result_at >= 1 && result_at <= 3) ef.park_nd(8 - result_at, result.N, result.D);
     };
 #pragma unroll 1
@@ -505,8 +507,17 @@ namespace {   // kernels: one private copy per translation unit (their code obje
 // Large variable-base batches, first half: per element, (DH: membership test, cofactor clearing,) table
 // construction into scratch slot `pos`.  Kept apart from the ladder so that the endomorphisms' register
 // appetite (256 VGPRs) does not set the ladder's occupancy.
+// Experiment (FQ_PREP_LDS=1): the table_endo flavour owns the CU's whole LDS (one block per CU, one wave per SIMD) and builds the
+// table the way the fused kernels do (build_table_endo_lds), without read-backs from the slot.  Measured SLOWER than two waves
+// per SIMD that wait on their read-backs: cfg4 -1.2 %, cfg5 -2.5 %, DH_endo at 2^20 -3 % (profiles/r02_split_route.txt) -- the
+// second wave hides more than the waits cost.  Off.
+#ifndef FQ_PREP_LDS
+#define FQ_PREP_LDS 0
+#endif
 template <int ALGO, bool DH>
 __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
+    constexpr bool USE_EF = ALGO == ENDO && FQ_PREP_LDS;
+    __shared__ __attribute__((aligned(16))) u32 lds_mem[USE_EF ? EF_LDS_U32 : 4];
     const u32 pos = blockIdx.x * BLOCK + threadIdx.x;
     if (pos >= (a.n_dev ? *a.n_dev : a.n)) return;
     const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
@@ -519,7 +530,15 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
         P = load_r1(a.points + 20 * (size_t)id);
     }
     u32* slot = a.scratch + (size_t)pos * PrebuiltSlots::SLOT;
-    if (ALGO == ENDO) build_table_endo<PrebuiltSlots>(P, slot); else build_table_windowed<PrebuiltSlots>(P, slot);
+    if constexpr (USE_EF) {
+        LdsEF ef;
+        ef.lane = reinterpret_cast<uint2*>(lds_mem) + threadIdx.x;
+        build_table_endo_lds<PrebuiltSlots, LdsEF, true>(P, slot, ef);
+    } else if (ALGO == ENDO) {
+        build_table_endo<PrebuiltSlots>(P, slot);
+    } else {
+        build_table_windowed<PrebuiltSlots>(P, slot);
+    }
 }
 
 // ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
