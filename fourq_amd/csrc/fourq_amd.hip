@@ -331,6 +331,7 @@ struct fourq_ctx {
     u64* table_packed = nullptr;   // 128 words
     u32* comb_limbs = nullptr;     // FOURQ_COMB_POINTS x 36 working limbs of the staged comb table
     u64* comb_packed = nullptr;    // FOURQ_COMB_POINTS x 12 words
+    uint64_t base_shadow[FOURQ_AFFINE_WORDS];   // dh_exchange: the base point while its (asynchronous) upload is in flight
     uint64_t table_shadow[FOURQ_TABLE_WORDS];   // host copies of what table_limbs / comb_limbs currently hold
     uint64_t comb_shadow[FOURQ_COMB_WORDS];
     bool table_staged = false, comb_staged = false;
@@ -531,12 +532,20 @@ void host_copy(char* dst, const char* src, size_t bytes) {
     if (threads <= 1) { memcpy(dst, src, bytes); return; }
     std::vector<std::thread> pool;
     const size_t per = (bytes / threads + 63) & ~(size_t)63;
-    for (size_t t = 1; t < threads; t++) {
-        const size_t lo = t * per, hi = (t + 1 == threads) ? bytes : (t + 1) * per;
-        pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+    size_t done_to = per;                      // [0, per) is this thread's slice; helpers take the rest
+    try {
+        pool.reserve(threads - 1);
+        for (size_t t = 1; t < threads; t++) {
+            const size_t lo = t * per, hi = (t + 1 == threads) ? bytes : (t + 1) * per;
+            pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+            done_to = hi;
+        }
+    } catch (...) {                            // no more threads to be had: nothing may cross the C ABI; copy the remainder here
+        done_to = pool.empty() ? per : done_to;
     }
     memcpy(dst, src, per);
     for (auto& th : pool) th.join();
+    if (done_to < bytes) memcpy(dst + done_to, src + done_to, bytes - done_to);
 }
 int grow(fourq_ctx* c, char** buf, size_t* have, size_t want, bool pinned) {
     if (want <= *have) return FOURQ_OK;
@@ -554,7 +563,17 @@ int ensure_work(fourq_ctx* c, size_t bytes) { return grow(c, &c->work, &c->work_
 
 using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev, size_t m)>;
 
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, const ChunkLaunch& launch);
 int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, const ChunkLaunch& launch) {
+    const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, launch);
+    if (rc != FOURQ_OK) {                      // a chunk failed half way: nothing of this call may still be in flight when the caller
+        (void)hipStreamSynchronize(c->copy_in);    // gets its buffers (and the context its slots) back
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->copy_out);
+    }
+    return rc;
+}
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, const ChunkLaunch& launch) {
     if (n_in > PIPE_MAX_ARRAYS || n_out > PIPE_MAX_ARRAYS || chunk == 0) return FOURQ_ERR_INVALID;
     if (chunk > n) chunk = n;
     size_t off_in[PIPE_MAX_ARRAYS], off_out[PIPE_MAX_ARRAYS], slot = 0;
@@ -644,7 +663,6 @@ int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* o
 
 // chunk of a host-pointer batch: whole generations of the kernels that will run it
 size_t pipe_chunk(const fourq_ctx* c, bool fused_route) { return fused_route ? c->lanes : c->lanes_w4; }
-
 int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out, size_t n) {
     if (!c || !scalars || !out || (!points && !table) || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
@@ -1094,7 +1112,8 @@ FQ_API int fourq_dh_exchange_batch_dev(fourq_ctx* c, const uint64_t* a, const ui
     uint64_t* mid = (uint64_t*)(c->work + n * 64);            // DH(b_i, base): the public keys
     uint8_t* st_first = (uint8_t*)(c->work + 2 * n * 64);
     uint64_t* one = (uint64_t*)(st_first + nb);
-    HIP_TRY(c, hipMemcpyAsync(one, base_affine, 64, hipMemcpyHostToDevice, c->stream));
+    if (base_affine != c->base_shadow) memcpy(c->base_shadow, base_affine, sizeof c->base_shadow);
+    HIP_TRY(c, hipMemcpyAsync(one, c->base_shadow, 64, hipMemcpyHostToDevice, c->stream));
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(broadcast_point_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, one, base, (u32)n);
     HIP_TRY(c, hipGetLastError());
@@ -1110,7 +1129,7 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     uint64_t base_copy[8];
-    memcpy(base_copy, base_affine, sizeof base_copy);         // the H2D copy of the base is asynchronous: keep a stable source
+    memcpy(base_copy, base_affine, sizeof base_copy);         // the caller's buffer is read once, here
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
