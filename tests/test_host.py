@@ -64,8 +64,8 @@ def test_abi_exports_every_declared_symbol():
     """include/fourq_amd.h is the contract: each declared function must be exported by the built
     library and bound by the ctypes layer with the same arity."""
     from fourq_amd import _lib
-    header = open(os.path.join(ROOT, "include", "fourq_amd.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    header_raw = open(os.path.join(ROOT, "include", "fourq_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header_raw, flags=re.S)
     decls = re.findall(r"\b(?:int|const char \*|void)\s*\*?\s*(fourq_\w+)\s*\(([^;{]*)\)\s*;", header)
     names = {n for n, _ in decls}
     assert len(names) >= 30
@@ -81,7 +81,16 @@ def test_abi_exports_every_declared_symbol():
     for key, val in re.findall(r"FOURQ_(\w+)\s*=\s*(\d+)", header):
         if key in _lib.PRIM:
             assert _lib.PRIM[key] == int(val), key
+    # ... and so do the sizes, limits and status codes the Python layer hard-codes
+    defines = dict(re.findall(r"#define\s+(FOURQ_\w+)\s+\(?([-\w* ]+?)\)?\s*(?:/\*|$)", header_raw, flags=re.M))
+    value = lambda k: eval(defines[k].replace("u", ""), {})
+    assert value("FOURQ_COMB_POINTS") == _lib.COMB_POINTS and value("FOURQ_COMB_WORDS") == _lib.COMB_WORDS
+    assert value("FOURQ_MAX_BATCH") == _lib.MAX_BATCH and value("FOURQ_BYTES_DECODE_BASE") == _lib.BYTES_DECODE_BASE
+    for name in ("OK", "ERR_INVALID", "ERR_NODEVICE", "ERR_NOMEM", "ERR_HIP", "DH_OK", "DH_NOT_ON_CURVE", "DH_NEUTRAL",
+                 "DECODE_OK", "DECODE_RESERVED_BIT", "DECODE_NOT_ON_CURVE", "DECODE_REF_ATTRIBUTE_ERROR"):
+        assert value("FOURQ_" + name) == getattr(_lib, name), name
     import ctypes
+    assert ctypes.sizeof(_lib.HostStats) == 48                     # struct fourq_host_stats: 2 doubles, 2 u64, u32 + 2 ints
     iw, ow = ctypes.c_size_t(), ctypes.c_size_t()
     for key, code in _lib.PRIM.items():
         assert lib.fourq_prim_words(code, ctypes.byref(iw), ctypes.byref(ow)) == 0 and iw.value and ow.value, key
