@@ -581,6 +581,42 @@ template <int ENTRIES, int COORDS> struct ScanRegs {
         return fe2_from_limbs(acc);
     }
 };
+// The fused constant-time kernels: N and D of the lane's eight entries in registers (loaded once from the HBM slot), E and F
+// scanned where the fused kernels keep them anyway, in the lane's private rows of LDS (kernels.hip.h, LdsEF) -- the LDS
+// addresses depend on the lane and the entry number, never on the digit.
+template <typename EFT> struct ScanSplit {
+    u32 nd[8][20];
+    EFT ef;
+    template <typename L, typename TP> FQ_DEV void load(const TP* tbl) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const Fe2<1> v = L::load(tbl + k * L::ENTRY + c * L::COORD);
+#pragma unroll
+                for (int i = 0; i < 5; i++) { nd[k][c * 10 + i] = v.re.l[i]; nd[k][c * 10 + 5 + i] = v.im.l[i]; }
+            }
+        }
+    }
+    FQ_DEV Fe2<1> coord(u32 digit, int c) const {
+        u32 acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (c < 2) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) masked_or<10>(acc, &nd[k][c * 10], eq_mask(digit, (u32)k));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {                       // two entries per round, as ScanMem
+                const Fe2<1> v0 = ef.get((u32)k, c - 2), v1 = ef.get((u32)k + 1, c - 2);
+                const u32 w0[10] = { v0.re.l[0], v0.re.l[1], v0.re.l[2], v0.re.l[3], v0.re.l[4], v0.im.l[0], v0.im.l[1], v0.im.l[2], v0.im.l[3], v0.im.l[4] };
+                const u32 w1[10] = { v1.re.l[0], v1.re.l[1], v1.re.l[2], v1.re.l[3], v1.re.l[4], v1.im.l[0], v1.im.l[1], v1.im.l[2], v1.im.l[3], v1.im.l[4] };
+                masked_or<10>(acc, w0, eq_mask(digit, (u32)k));
+                masked_or<10>(acc, w1, eq_mask(digit, (u32)k + 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return fe2_from_limbs(acc);
+    }
+};
 // Q + (+-T[digit]), every entry read: the constant-time form of add_table
 template <int CH, typename SRC> FQ_DEV R1 add_scan(const R1& q, const SRC& src, u32 digit, u32 neg_mask) {
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);

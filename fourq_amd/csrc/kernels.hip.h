@@ -54,6 +54,9 @@ constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k
 #ifndef FQ_FUSED_LDS_EF
 #define FQ_FUSED_LDS_EF 1
 #endif
+#ifndef FQ_CT_LDS_EF            // the constant-time fused kernels too (ScanSplit, curve.hip.h)
+#define FQ_CT_LDS_EF 1
+#endif
 constexpr int EF_LDS_U32 = 8 * 2 * 5 * 2 * 256;               // dwords: 163 840 bytes
 struct LdsEF {
     static constexpr bool ON = true;
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
 template <int ALGO, int SRC, bool DH, bool DEFER = false, bool CT = false>
 __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
     static_assert(!DEFER || DH, "only DH outputs are normalised");
-    constexpr bool USE_EF = SRC == FUSED && !CT && FQ_FUSED_LDS_EF && FQ_FUSED_PRELOAD;     // LdsEF: the CU's whole LDS for one block
+    constexpr bool USE_EF = SRC == FUSED && FQ_FUSED_LDS_EF && FQ_FUSED_PRELOAD && (!CT || FQ_CT_LDS_EF);     // LdsEF: the CU's whole LDS for one block
     __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : (USE_EF ? EF_LDS_U32 : 4)];
     using EF = typename std::conditional<USE_EF, LdsEF, NoEF>::type;
     EF ef;
@@ -617,7 +620,12 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
                 e = recode(v);
             }
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
-            if constexpr (CT && SRC == FUSED) {
+            if constexpr (CT && SRC == FUSED && USE_EF) {
+                ScanSplit<EF> regs;
+                regs.ef = ef;
+                regs.template load<L>(tbl);
+                Q = ladder_endo_scan<CH>(e, regs);
+            } else if constexpr (CT && SRC == FUSED) {
                 ScanRegs<8, 4> regs;
                 regs.template load<L>(tbl);
                 Q = ladder_endo_scan<CH>(e, regs);
@@ -629,7 +637,12 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         } else {
             WinScalar w = win_reduce(m);
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
-            if constexpr (CT && SRC == FUSED) {
+            if constexpr (CT && SRC == FUSED && USE_EF) {
+                ScanSplit<EF> regs;
+                regs.ef = ef;
+                regs.template load<L>(tbl);
+                Q = ladder_windowed_scan<CH>(w, regs);
+            } else if constexpr (CT && SRC == FUSED) {
                 ScanRegs<8, 4> regs;
                 regs.template load<L>(tbl);
                 Q = ladder_windowed_scan<CH>(w, regs);
