@@ -355,10 +355,11 @@ struct LimbSlots {
     template <typename P> static FQ_DEV Fe2<1> load(const P* src) { return load_fe2_limbs(src); }
     template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) { store_fe2_limbs(dst, v); }
 };
-// N and D only (the fused kernels keep E and F in LDS, kernels.hip.h LdsEF): 96-byte entries, each inside two sectors, and a
-// 1 088-byte slot: 8 192 lanes of an XCD then keep 6.3 MB of entries, of which its 4 MiB L2 holds most
+// N and D only (the fused kernels keep E and F in LDS, kernels.hip.h LdsEF, and park table_endo's working values there too):
+// 96-byte entries, each inside two sectors, 768-byte slots: 8 192 lanes of an XCD keep 6.3 MB of entries, of which its 4 MiB L2
+// holds most.  PARK_P / PARK_Q exist for the builders that park in the slot (none does with this layout).
 struct NDSlots {
-    static constexpr int COORD = COORD_U32, ENTRY = 2 * COORD_U32, PARK_P = 8 * 2 * COORD_U32, PARK_Q = 8 * 2 * COORD_U32 + 40, SLOT = 272;
+    static constexpr int COORD = COORD_U32, ENTRY = 2 * COORD_U32, PARK_P = 0, PARK_Q = 0, SLOT = 8 * 2 * COORD_U32;
     template <typename P> static FQ_DEV Fe2<1> load(const P* src) { return load_fe2_limbs(src); }
     template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) { store_fe2_limbs(dst, v); }
 };

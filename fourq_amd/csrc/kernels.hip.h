@@ -204,6 +204,7 @@ template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_wi
 // Q are parked in the lane's scratch slot so that they do not pin 60 VGPRs across the endomorphisms.
 template <typename L = LimbSlots> FQ_DEV void build_table_endo(const R1& P, u32* slot) {
     constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
+    static_assert(SLOT_Q > SLOT_P && SLOT_Q + 30 <= L::SLOT, "this builder parks two points in the slot");
     store_r2<L>(slot, r1_to_r2(P));
     store_xyz(slot + SLOT_P, P.X, P.Y, P.Z);
 #pragma unroll 1
@@ -353,6 +354,7 @@ FQ_DEV void memory_point() {
 }
 template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot, const EF& ef = EF()) {
     constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
+    static_assert(SLOT_Q > SLOT_P && SLOT_Q + 30 <= L::SLOT, "this builder parks two points in the slot");
     R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
     int result_at = 0;
     Fe2<1> X = P.X, Y = P.Y, Z = P.Z;          // step 0: P; step 1: tau(P), parked by step 0; step 2: phi(P)
