@@ -16,6 +16,8 @@ Files written
   mul.json        MUL_windowed / MUL_endo raw R1 outputs (with/without table, edge scalars)
   dh.json         DH_windowed / DH_endo outputs and both rejection cases
   wire.json       encode / decode round trips, arbitrary strings, malformed inputs
+  protocol.json   GFp.select / GFp2.select, and the protocol step encode(DH(m, decode(B))) composed from the reference's
+                  own three functions (draft-ladd-cfrg-4q.md:707-723), incl. every way it fails
 """
 import json
 import os
@@ -346,7 +348,48 @@ def make_wire():
     return out
 
 
+# ----------------------------------------------------------------------------- protocol.json
+def make_protocol():
+    """GFp.select / GFp2.select (fields.py:59-64, :236-238) and the Diffie-Hellman step over the wire: decode the peer's
+    32-byte key, DH_<kind> with the scalar, encode the result -- the reference's own functions composed
+    (curve4q.py:49-96, :446-468, :41-46)."""
+    rng = random.Random(1008)
+    out = {"select": [], "select2": [], "dh_bytes": []}
+    for _ in range(24):
+        x, y = rng.getrandbits(127), rng.getrandbits(127)
+        a, b = (rng.getrandbits(127), rng.getrandbits(127)), (rng.getrandbits(127), rng.getrandbits(127))
+        for c in (0, 1):
+            out["select"].append(hx([c, x, y, F.GFp.select(c, x, y)]))
+            out["select2"].append(hx([c, a, b, F.GFp2.select(c, a, b)]))
+    G1 = C.AffineToR1(C.Gx, C.Gy)
+    P392 = ((0x1318020702DE23BC3C9B73C751B4B192, 0x77AB39A7D8990C0A18E3C409FBD81A95),
+            (0x515854B6D19CC2DA1EA2B43B5121A22E, 0x763F89E129497361D74DFF5063E66682))
+    keys = [bytes(C.encode(*C.R1toAffine(C.MUL_endo(rng.getrandbits(256), G1)))) for _ in range(20)]
+    keys += [bytes(C.encode(C.Gx, C.Gy)), bytes(C.encode(*P392)), bytes(C.encode(C.Ox, C.Oy)), bytes(31) + b"\x80",
+             bytes([0xFF] * 15 + [0x7F] + [0] * 16)]
+    for _ in range(24):                                   # arbitrary strings: most decode to some point of the curve, some do not
+        raw = bytearray(rng.getrandbits(256).to_bytes(32, "little"))
+        raw[15] &= 0x7F
+        keys.append(bytes(raw))
+    scalars = [rng.getrandbits(256) for _ in keys]
+    scalars[0], scalars[1], scalars[20] = 0, C.N, C.N     # neutral results from valid keys
+    for m, B in zip(scalars, keys):
+        row = [hx(m), B.hex()]
+        for dh in (C.DH_endo, C.DH_windowed):
+            try:
+                row.append(["ok", bytes(C.encode(*dh(m, C.decode(bytearray(B))))).hex()])
+            except Exception as exc:
+                row.append([type(exc).__name__, str(exc)])
+        out["dh_bytes"].append(row)
+    out["_layout"] = {"select": "c,x,y,GFp.select(c,x,y)", "select2": "c,a,b,GFp2.select(c,a,b)",
+                      "dh_bytes": "m, key hex, [ok, encode(DH_endo(m, decode(key))) hex | exception type, message], the same for DH_windowed"}
+    return out
+
+
 if __name__ == "__main__":
+    if "--only-protocol" in sys.argv:                     # the other files are unchanged since round 1
+        dump("protocol.json", make_protocol())
+        raise SystemExit(0)
     dump("kat.json", hx(make_kat()))
     dump("field.json", make_field())
     dump("group.json", make_group())
@@ -355,3 +398,4 @@ if __name__ == "__main__":
     dump("mul.json", make_mul())
     dump("dh.json", make_dh())
     dump("wire.json", make_wire())
+    dump("protocol.json", make_protocol())

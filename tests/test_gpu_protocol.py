@@ -216,3 +216,32 @@ def test_select_and_dh_core_with_any_callable(golden):
         with pytest.raises(Exception) as ei:
             c.DH_core(int(m, 16), unhex(Pt), my_mul)
         assert str(ei.value) == msg
+
+
+def test_protocol_vectors_of_the_reference(eng, golden):
+    """tests/golden/protocol.json was produced by the REFERENCE composing its own decode, DH_* and encode: the one-call
+    device path must give the same 32 bytes, or the status of the same failure."""
+    g = golden("protocol.json", raw=True)
+    rows = g["dh_bytes"]
+    s = codec.pack_scalars([int(r[0], 16) for r in rows])
+    keys = np.frombuffer(b"".join(bytes.fromhex(r[1]) for r in rows), dtype=np.uint8).reshape(-1, 32)
+    status_of = {"Malformed point: reserved bit is not zero": 16 + _lib.DECODE_RESERVED_BIT, "Point not on curve": 16 + _lib.DECODE_NOT_ON_CURVE,
+                 "type object 'GFp' has no attribute 'two'": 16 + _lib.DECODE_REF_ATTRIBUTE_ERROR,
+                 "DH computation resulted in neutral point": _lib.DH_NEUTRAL}
+    for kind, col in (("endo", 2), ("windowed", 3)):
+        out, st = eng.dh_bytes(s, keys, kind=kind)
+        for r, got, code in zip(rows, out, st):
+            if r[col][0] == "ok":
+                assert code == 0 and bytes(got).hex() == r[col][1]
+            else:
+                assert code == status_of[r[col][1]] and not got.any()
+    assert len({r[2][1] for r in rows if r[2][0] != "ok"}) == 4          # all four kinds of failure are in the fixture
+
+
+def test_select_vectors_of_the_reference(golden):
+    from fourq_amd import curve4q as c
+    g = golden("protocol.json", raw=True)
+    for bit, x, y, r in unhex(g["select"])[:16]:
+        assert c.GFp.select(bit, x, y) == r
+    for bit, a, b, r in unhex(g["select2"])[:16]:
+        assert c.GFp2.select(bit, a, b) == r

@@ -225,3 +225,20 @@ def test_wire_vectors(golden):
             with pytest.raises(Exception) as ei:
                 o.decode(raw)
             assert (type(ei.value).__name__, str(ei.value)) == (row[1], row[2])
+
+
+def test_protocol_vectors(golden):
+    """protocol.json: the reference's GFp.select / GFp2.select and its own composition encode(DH(m, decode(key))), every
+    failure included (draft-ladd-cfrg-4q.md:707-723)."""
+    g = golden("protocol.json", raw=True)
+    for c, x, y, r in unhex(g["select"]):
+        assert o.fp_select(c, x, y) == r
+    for c, a, b, r in unhex(g["select2"]):
+        assert o.f2_select(c, a, b) == r
+    for m, key, endo, win in g["dh_bytes"]:
+        for dh, want in ((o.DH_endo, endo), (o.DH_windowed, win)):
+            try:
+                got = ["ok", bytes(o.encode(*dh(int(m, 16), o.decode(bytes.fromhex(key))))).hex()]
+            except Exception as exc:
+                got = [type(exc).__name__, str(exc)]
+            assert got == want, (m, key)
