@@ -244,12 +244,15 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo(const R1& P, u32*
 // Which ladders run on signed limbs (fp127.hip.h, "signed flavour"; 5 % fewer instructions per step).  Measured
 // per kernel against the unsigned chained ladder (same-box A/B): the LDS ladders gain 1-5 % and the
 // mixed-batch PREBUILT ladder 2 %; the fused kernels lose 3 %, the split windowed ladder 2 %, the split DH ladder is
-// neutral.  Hence: LDS ladders and the non-DH ENDO PREBUILT ladder only.
+// neutral (with packed entries, round 2: +1 %).  Hence: LDS ladders and the ENDO PREBUILT ladders.
 #ifndef FQ_SIGNED_LADDER
 #define FQ_SIGNED_LADDER 1
 #endif
+#ifndef FQ_SIGNED_DH_PREBUILT          // the split DH ladder too: neutral in round 1, +1 % on cfg4 with packed entries (r02_split_route.txt)
+#define FQ_SIGNED_DH_PREBUILT 1
+#endif
 template <int ALGO, int SRC, bool DH> constexpr bool signed_ladder() {
-    return FQ_SIGNED_LADDER && (SRC == LDS || (SRC == PREBUILT && ALGO == ENDO && !DH));
+    return FQ_SIGNED_LADDER && (SRC == LDS || (SRC == PREBUILT && ALGO == ENDO && (!DH || FQ_SIGNED_DH_PREBUILT)));
 }
 #ifndef FQ_FUSED_PRELOAD
 #define FQ_FUSED_PRELOAD 1
