@@ -251,8 +251,18 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo(const R1& P, u32*
 #ifndef FQ_SIGNED_DH_PREBUILT          // the split DH ladder too: neutral in round 1, +1 % on cfg4 with packed entries (r02_split_route.txt)
 #define FQ_SIGNED_DH_PREBUILT 1
 #endif
+// Round 1 measured the fused ladders -3 % and the split windowed ladder -2 % on signed limbs; with E, F in LDS, compact N, D slots
+// and packed entries (round 2) the same switch measures +4.4 % on the headline kernel and +2.8 % on MUL_windowed at 2^20
+// (profiles/r02_signed_ladders.txt): every ladder now runs signed.
+#ifndef FQ_SIGNED_FUSED
+#define FQ_SIGNED_FUSED 1
+#endif
+#ifndef FQ_SIGNED_WIN_PREBUILT
+#define FQ_SIGNED_WIN_PREBUILT 1
+#endif
 template <int ALGO, int SRC, bool DH> constexpr bool signed_ladder() {
-    return FQ_SIGNED_LADDER && (SRC == LDS || (SRC == PREBUILT && ALGO == ENDO && (!DH || FQ_SIGNED_DH_PREBUILT)));
+    return FQ_SIGNED_LADDER && (SRC == LDS || (SRC == PREBUILT && ALGO == ENDO && (!DH || FQ_SIGNED_DH_PREBUILT)) ||
+                                (SRC == PREBUILT && ALGO == WINDOWED && FQ_SIGNED_WIN_PREBUILT) || (SRC == FUSED && FQ_SIGNED_FUSED));
 }
 #ifndef FQ_FUSED_PRELOAD
 #define FQ_FUSED_PRELOAD 1
