@@ -407,10 +407,11 @@ template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs
     return FOURQ_OK;
 }
 // Which variable-base batches take the two-kernel route (prep_kernel + ladder_kernel<PREBUILT>, 4 waves per SIMD).
-// Measured on MI355X with packed 128-byte table entries (profiles/r02_split_route.txt): MUL_windowed and DH_* gain
-// 2-8 % from two resident generations of the fused kernels upwards; plain MUL_endo, whose 64-step ladder hardly
-// amortises the second launch, gains 1-3 % from four generations upwards and nothing below.  (With 192-byte entries a
-// round's tables, 486 MB, fell out of the Infinity Cache and plain MUL_endo lost 7 % on this route.)
+// Measured on MI355X (profiles/r02_split_route.txt): MUL_windowed gains 8 % and DH_* 2-3 % from two resident generations of
+// the fused kernels upwards.  Plain MUL_endo, whose 64-step ladder hardly amortises the second launch, lost 7 % on this route
+// in round 1 (192-byte entries: a round's tables, 486 MB, fell out of the Infinity Cache), gained 1-3 % once the entries were
+// packed, and loses 3-4 % again since the fused kernel keeps E, F in LDS and runs on signed limbs (5.21 ms against 5.43 at
+// 2^20): it stays fused (FOURQ_SPLIT_ENDO_MIN = smallest batch that would take the route, 0 = never).
 bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
     if (c->ct) return false;        // constant-time mode keeps the lane's table in registers: fused kernels only
     if (algo == WINDOWED || dh || c->split_all) return n >= c->split_min;
@@ -757,7 +758,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         c->split_min = 2 * c->lanes;                       // below two full waves of fused work the second launch does not pay
         if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
-        c->split_endo_min = 4 * c->lanes;
+        c->split_endo_min = 0;
         if (const char* env = getenv("FOURQ_SPLIT_ENDO_MIN")) { long v = atol(env); if (v >= 0) c->split_endo_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;

@@ -27,7 +27,7 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     R1 P = load_r1(points + 20 * (size_t)id);
     u32* slot = scratch + (size_t)id * NDSlots::SLOT;
     uint64_t t1 = stamp();
-    if (VARIANT != 2) { if (FQ_TABLE_LDS_PARK) build_table_endo_lds<NDSlots>(P, slot, ef); else build_table_endo_lone_wave<NDSlots>(P, slot, ef); }
+    if (VARIANT != 2) build_table_endo_lds<NDSlots>(P, slot, ef);
     else { for (int kk = 0; kk < 8; kk++) { R2 t = r1_to_r2(P); ef.put(kk, t); } }      // LDS filled, HBM slot left from the previous launch
     uint64_t t2 = stamp();
     u64 v[4];
@@ -35,7 +35,7 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     EndoDigits e = recode(v);
     if (VARIANT == 1) { e.d[0] = e.d[1] = e.d[2] = 0; e.top = 0; }
     uint64_t t3 = stamp();
-    R1 Q = ladder_endo<1, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);
+    R1 Q = ladder_endo<FQ_SIGNED_FUSED ? 2 : 1, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);
     uint64_t t4 = stamp();
     u64 o[20];
     store_r1(o, Q);
