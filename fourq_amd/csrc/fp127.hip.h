@@ -375,7 +375,9 @@ FQ_DEV Fe<1> fe_sqr_n(Fe<1> x, int n) {
     for (int i = 0; i < n; i++) x = fe_sqr(x);
     return x;
 }
-__device__ __noinline__ Fe<1> fe_inv(Fe<1> x) {
+// the chain itself, inlined where the call would cost more than its code: a caller with many live values (normalize_kernel)
+// otherwise spills them around the call (656 bytes of scratch per lane at K = 8)
+FQ_DEV Fe<1> fe_inv_inline(Fe<1> x) {
     Fe<1> x2 = fe_mul(x, fe_sqr(x));             // 2^2 - 1
     Fe<1> x4 = fe_mul(x2, fe_sqr_n(x2, 2));      // 2^4 - 1
     Fe<1> x8 = fe_mul(x4, fe_sqr_n(x4, 4));      // 2^8 - 1
@@ -389,6 +391,7 @@ __device__ __noinline__ Fe<1> fe_inv(Fe<1> x) {
     t = fe_mul(fe_sqr(t), x);                    // 2^125 - 1
     return fe_mul(fe_sqr_n(t, 2), x);            // 2^127 - 3
 }
+__device__ __noinline__ Fe<1> fe_inv(Fe<1> x) { return fe_inv_inline(x); }
 // x^(2^125 - 1) = 1/sqrt(x) for squares (fields.py:108-122); any addition chain gives the same residue
 __device__ __noinline__ Fe<1> fe_invsqrt(Fe<1> x) {
     Fe<1> x2 = fe_mul(x, fe_sqr(x));             // 2^2 - 1

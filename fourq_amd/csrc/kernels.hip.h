@@ -781,25 +781,28 @@ __global__ __launch_bounds__(BLOCK) void normalize_kernel(const uint4* proj, u32
     const u32 T = (n + K - 1) / K;
     const u32 t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= T) return;
+    // every loop over the K elements is unrolled in full: left to its size heuristics the compiler keeps z[], nz[] and pre[] in
+    // scratch memory and walks them by a run-time index (656 bytes per lane at K = 8), a memory round trip per use in a kernel
+    // that is nothing but one dependent chain per lane
     Fe<1> one;
     one.l[0] = 1; one.l[1] = one.l[2] = one.l[3] = one.l[4] = 0;
     Fe2<1> z[K];
     uint8_t st[K];
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int j = 0; j < K; j++) {                     // all loads first: the lane's K elements are K separate cache lines
         const u32 id = t + (u32)j * T, at = id < n ? id : t;
         z[j] = load_proj_z(proj, stride, at);
         st[j] = id < n ? status[at] : (uint8_t)FOURQ_DH_NOT_ON_CURVE;
     }
     Fe<1> nz[K], pre[K];
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int j = 0; j < K; j++) {
         Fe<1> norm = fe_carry(fe_add(fe_sqr(z[j].re), fe_sqr(z[j].im)));
         nz[j] = fe_select(st[j] == FOURQ_DH_OK ? ~0u : 0u, norm, one);
         if (j == 0) pre[0] = nz[0]; else pre[j] = fe_mul(pre[j - 1], nz[j]);
     }
-    Fe<1> inv = fe_inv(pre[K - 1]);
-#pragma unroll
+    Fe<1> inv = fe_inv_inline(pre[K - 1]);
+#pragma clang loop unroll(full)
     for (int j = K - 1; j >= 0; j--) {
         const u32 id = t + (u32)j * T, at = id < n ? id : t;
         Fe2<1> X, Y, zi;
@@ -815,7 +818,7 @@ __global__ __launch_bounds__(BLOCK) void normalize_kernel(const uint4* proj, u32
         if (s == FOURQ_DH_OK && (o[0] | o[1] | o[2] | o[3] | o[5] | o[6] | o[7]) == 0 && o[4] == 1) s = FOURQ_DH_NEUTRAL;   // curve4q.py:459-460
         if (id < n) {
             uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)id);
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int k = 0; k < 4; k++) {
                 u64 lo = s ? 0 : o[2 * k], hi = s ? 0 : o[2 * k + 1];
                 dst[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
