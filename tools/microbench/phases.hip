@@ -4,6 +4,7 @@
 //   0  the kernel as shipped (N, D gathered from the lane's HBM slot, E, F from LDS)
 //   1  the ladder gathers ALWAYS entry 0 (same instruction stream, all of a lane's gathers hit one address)
 //   2  no table construction (slots pre-filled by variant 0's previous launch): ladder only
+//   3  table construction as prep_kernel would do it with the LDS scheme: whole packed entries to the slot (FULL)
 // Diagnostic build, never part of the product:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -o phases phases.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,13 +22,15 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     __shared__ __attribute__((aligned(16))) u32 lds_mem[EF_LDS_U32];
     LdsEF ef; ef.lane = reinterpret_cast<uint2*>(lds_mem) + threadIdx.x;
     const u32 id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= (1u << 16)) return;                  // "dead" blocks of an over-sized grid (variant 3 is launched with 512 blocks)
     uint64_t t0 = stamp();
     u64 m[4];
     load_scalar(scalars + 4 * (size_t)id, m);
     R1 P = load_r1(points + 20 * (size_t)id);
     u32* slot = scratch + (size_t)id * NDSlots::SLOT;
     uint64_t t1 = stamp();
-    if (VARIANT != 2) build_table_endo_lds<NDSlots>(P, slot, ef);
+    if (VARIANT == 3) build_table_endo_lds<PackedSlots, LdsEF, true>(P, scratch + (size_t)id * PackedSlots::SLOT, ef);
+    else if (VARIANT != 2) build_table_endo_lds<NDSlots>(P, slot, ef);
     else { for (int kk = 0; kk < 8; kk++) { R2 t = r1_to_r2(P); ef.put(kk, t); } }      // LDS filled, HBM slot left from the previous launch
     uint64_t t2 = stamp();
     u64 v[4];
@@ -52,21 +55,22 @@ int main() {
     const int n = 1 << 16;
     u64 *s, *p, *o; u32* scr; uint64_t* st;
     CHECK(hipMalloc(&s, n * 32)); CHECK(hipMalloc(&p, n * 160)); CHECK(hipMalloc(&o, n * 160));
-    CHECK(hipMalloc(&scr, (size_t)n * NDSlots::SLOT * 4)); CHECK(hipMalloc(&st, 1024 * 64));
+    CHECK(hipMalloc(&scr, (size_t)n * PackedSlots::SLOT * 4)); CHECK(hipMalloc(&st, 1024 * 64));
     std::vector<u64> hs(n * 4), hp(n * 20);
     uint64_t x = 88172645463325252ull;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     for (auto& v : hs) v = rnd();
     for (size_t i = 0; i < hp.size(); i++) hp[i] = (i & 1) ? (rnd() >> 1) : rnd();          // any residues: timing does not care whether they are points
     CHECK(hipMemcpy(s, hs.data(), n * 32, hipMemcpyHostToDevice)); CHECK(hipMemcpy(p, hp.data(), n * 160, hipMemcpyHostToDevice));
-    const char* names[3] = { "as shipped", "ladder gathers always entry 0", "no table construction" };
-    for (int variant = 0; variant < 3; variant++) {
+    const char* names[4] = { "as shipped", "ladder gathers always entry 0", "no table construction", "table to packed slots (FULL)" };
+    for (int variant = 0; variant < 4; variant++) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); float ms = 0, best = 1e9;
         for (int rep = 0; rep < 60; rep++) {
             CHECK(hipEventRecord(e0));
             if (variant == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
             else if (variant == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
-            else hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
+            else if (variant == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
+            else hipLaunchKernelGGL(k<3>, dim3(512), dim3(256), 0, 0, s, p, o, scr, st);
             CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 40 && ms < best) best = ms;
         }
