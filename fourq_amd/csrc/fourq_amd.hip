@@ -351,7 +351,7 @@ struct fourq_ctx {
     // H2D copy -> kernels -> D2H copy on three streams
     hipStream_t copy_in = nullptr, copy_out = nullptr;
     hipEvent_t in_done[3] = {}, kernels_done[3] = {}, out_done[3] = {};
-    std::vector<hipEvent_t> ticks;     // timing events around every copy of the last call
+    std::vector<hipEvent_t> ticks;     // timing events around the copies of the chunks in flight: four per pipeline slot
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
     fourq_host_stats host_stats = {};
@@ -601,7 +601,7 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
     if (rc) return rc;
     if (bounce && (rc = grow(c, &c->pipe_pin, &c->pipe_pin_bytes, slot * slots, true))) return rc;
-    while (c->ticks.size() < 4 * chunks) {
+    while (c->ticks.size() < 4 * (size_t)PIPE_SLOTS) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreate(&e));
         c->ticks.push_back(e);
@@ -610,6 +610,11 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     auto drain = [&](size_t k) -> int {          // chunk k has left the device: hand a pageable caller its bytes
         const int b = (int)(k % slots);
         HIP_TRY(c, hipEventSynchronize(c->out_done[b]));
+        float ms = 0;                                // the slot's timing events belong to chunk k until the slot is reused
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * b], c->ticks[4 * b + 1]));
+        st.h2d_ms += ms;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * b + 2], c->ticks[4 * b + 3]));
+        st.d2h_ms += ms;
         const size_t off = k * chunk, m = n - off < chunk ? n - off : chunk;
         for (int i = 0; i < n_out; i++)
             if (!pin_out[i]) host_copy(out[i].dst + off * out[i].stride, c->pipe_pin + (size_t)b * slot + off_out[i], m * out[i].stride);
@@ -626,38 +631,31 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             din[i] = dev + off_in[i];
             if (!pin_in[i]) host_copy(pin + off_in[i], in[i].src + off * in[i].stride, m * in[i].stride);
         }
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * k], c->copy_in));
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * b], c->copy_in));
         for (int i = 0; i < n_in; i++) {
             const char* src = pin_in[i] ? in[i].src + off * in[i].stride : pin + off_in[i];
             HIP_TRY(c, hipMemcpyAsync(din[i], src, m * in[i].stride, hipMemcpyHostToDevice, c->copy_in));
             st.h2d_bytes += m * in[i].stride;
         }
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 1], c->copy_in));
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * b + 1], c->copy_in));
         HIP_TRY(c, hipEventRecord(c->in_done[b], c->copy_in));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_done[b], 0));
         for (int i = 0; i < n_out; i++) dout[i] = dev + off_out[i];
         if ((rc = launch(din, dout, m))) return rc;
         HIP_TRY(c, hipEventRecord(c->kernels_done[b], c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->copy_out, c->kernels_done[b], 0));
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 2], c->copy_out));
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * b + 2], c->copy_out));
         for (int i = 0; i < n_out; i++) {
             char* dst = pin_out[i] ? out[i].dst + off * out[i].stride : pin + off_out[i];
             HIP_TRY(c, hipMemcpyAsync(dst, dout[i], m * out[i].stride, hipMemcpyDeviceToHost, c->copy_out));
             st.d2h_bytes += m * out[i].stride;
         }
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 3], c->copy_out));
+        HIP_TRY(c, hipEventRecord(c->ticks[4 * b + 3], c->copy_out));
         HIP_TRY(c, hipEventRecord(c->out_done[b], c->copy_out));
     }
     for (size_t k = chunks > (size_t)slots ? chunks - slots : 0; k < chunks; k++)
         if ((rc = drain(k))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (size_t k = 0; k < chunks; k++) {
-        float ms = 0;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k], c->ticks[4 * k + 1]));
-        st.h2d_ms += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k + 2], c->ticks[4 * k + 3]));
-        st.d2h_ms += ms;
-    }
     c->host_stats = st;
     return FOURQ_OK;
 }
