@@ -1,0 +1,63 @@
+"""The C ABI from C: include/fourq_amd.h compiles as C99 (CPU test) and a plain C host program linked against
+libfourq_amd.so reproduces the oracle's MUL_endo / DH_endo outputs bit for bit (GPU test).  This is the binding a
+maintainer of another host language would write."""
+import os
+import random
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import curve4q_oracle as o
+import oracle_c as oc
+from conftest import ROOT
+from fourq_amd import codec
+from fourq_amd.build import build_library
+
+HEADER_DIR = os.path.join(ROOT, "include")
+SRC = os.path.join(ROOT, "tests", "c", "cabi_check.c")
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs a C compiler")
+def test_header_is_plain_c99_and_cxx(tmp_path):
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "fourq_amd.h"\nint main(void) { return FOURQ_TABLE_WORDS == 128 && sizeof(fourq_host_stats) == 48 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", HEADER_DIR, "-c", "-o", str(tmp_path / "probe.o"), str(probe)], check=True)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", HEADER_DIR, "-fsyntax-only", SRC], check=True)
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-I", HEADER_DIR, "-x", "c++", "-fsyntax-only", str(probe)], check=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs a C compiler")
+def test_c_host_program_matches_the_oracle(tmp_path):
+    lib = build_library()
+    exe = str(tmp_path / "cabi_check")
+    libdir = os.path.dirname(lib)
+    subprocess.run(["gcc", "-std=c99", "-O1", "-I", HEADER_DIR, "-o", exe, SRC, "-L", libdir, "-lfourq_amd", "-Wl,-rpath," + libdir], check=True)
+    n = 300
+    rng = random.Random(4711)
+    s = np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+    G1 = codec.pack_point(o.AffineToR1(o.Gx, o.Gy))
+    te = oc.table(oc.ENDO, G1)
+    k = np.frombuffer(rng.getrandbits(256 * n).to_bytes(32 * n, "little"), dtype="<u8").reshape(n, 4).copy()
+    pts = oc.mul(oc.ENDO, k, None, te)                                   # projective N-torsion points
+    want = oc.mul(oc.ENDO, s, pts)
+    g = np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0)
+    aff, st0 = oc.dh(oc.ENDO, k, g)
+    aff[3] = 0                                                          # one point off the curve
+    want_dh, want_st = oc.dh(oc.ENDO, s, aff)
+    assert want_st[3] == 1 and not st0.any()
+    path = tmp_path / "vectors.bin"
+    with open(path, "wb") as fh:
+        fh.write(np.uint64(n).tobytes())
+        for a in (s, pts, want, aff, want_dh):
+            fh.write(np.ascontiguousarray(a, dtype="<u8").tobytes())
+        fh.write(want_st.astype(np.uint8).tobytes())
+    env = dict(os.environ)
+    # the C program brings no PyTorch: the library then binds the system HIP runtime (/opt/rocm/lib)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    proc = subprocess.run([exe, str(path)], capture_output=True, text=True, env=env)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert "bit-exact through the C ABI" in proc.stdout
