@@ -261,3 +261,40 @@ def test_batches_beyond_the_abi_limit_are_refused(eng):
         st = np.empty(16, dtype=np.uint8)
         assert lib.fourq_dh_endo_batch(eng._ctx, ptr(s), ptr(pts), None, ptr(out), ptr(st), n) == _lib.ERR_INVALID
     assert np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
+
+
+def test_dev_entry_points_can_be_captured_into_a_hip_graph(eng):
+    """The _dev entry points only enqueue kernels on the context's stream, so a caller can capture them into a HIP graph
+    (torch.cuda.CUDAGraph) and replay it: here a variable-base MUL_endo followed by a fixed-base one that overwrites the first
+    one's input, replayed twice.  (Call each route once before capturing: the first call stages tables / sizes buffers.)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 3000
+    s_h, k_h = seeded_scalars(61, n), seeded_scalars(62, n)
+    te = oc.table(oc.ENDO, codec.pack_point(G1))
+    p_h = oc.mul(oc.ENDO, k_h, None, te)
+    s = torch.from_numpy(s_h.view(np.int64)).to(dev)
+    p = torch.from_numpy(p_h.view(np.int64)).to(dev)
+    out = torch.empty((n, 20), dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    eng.set_stream(side.cuda_stream)
+    try:
+        eng.mul_endo_fixed_dev(s, te, out, n)              # stages the table outside the capture
+        eng.sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            eng.mul_endo_dev(s, p, out, n)
+            eng.mul_endo_fixed_dev(s, te, p, n)
+            graph.capture_end()
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), oc.mul(oc.ENDO, s_h, p_h))
+        p2 = p.cpu().numpy().view(np.uint64).copy()        # the replay left [s_i]G in `p`
+        assert np.array_equal(p2, oc.mul(oc.ENDO, s_h, None, te))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), oc.mul(oc.ENDO, s_h, p2))
+    finally:
+        eng.set_stream(None)
