@@ -1,0 +1,58 @@
+"""The driver's contract with bench.py, checked on the GPU box: one JSON line on stdout with the agreed keys, the headline
+metric on BASELINE.json's configuration, `roofline` and `cpu_baseline` objects, a parity verdict, and the nested records
+of configs 3-5.  Short runs (few steps); the numbers themselves are not asserted, their consistency is."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*args):
+    env = dict(os.environ)
+    env["FOURQ_BENCH_SETTLE_MS"] = "10"
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "stdout must carry exactly one line: %r" % lines[:3]
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_keys():
+    line = run_bench("--steps", "20", "--warmup", "2")
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                     ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("valu_roofline", dict), ("parity", dict),
+                     ("configs", dict), ("pcie_inclusive", dict)):
+        assert isinstance(line[key], typ), key
+    assert line["vs_baseline"] is None and line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 2
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic" and line["dtype"] == "u64"
+    assert "configs[1]" in line["config"]["workload"] and line["config"]["batch_per_gpu"] == 1 << 16
+    assert abs(line["value"] - (1 << 16) / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.01       # units / time, whole job
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert r["algorithmic_bytes_per_launch"] == 352 << 16 and r["kernel_ms"] <= line["ms_per_step"] * 1.05
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01
+    v = line["valu_roofline"]
+    assert 0 < v["algorithmic_frac"] < v["executed_frac"] < 1 and v["algorithmic_mads_per_unit"] == 49440
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "oracle/curve4q_oracle.py" in c["sample"]
+    assert c["c_restatement"]["threads"] == c["c_restatement"]["cores"]                              # OpenMP took the thread count
+    assert line["parity"]["ok"] is True and line["parity"]["units"] == 1 << 16
+    assert set(line["configs"]) == {"cfg3", "cfg4", "cfg5"}
+    for name, rec in line["configs"].items():
+        assert rec["parity"]["ok"] is True and rec["ms_per_step"] > 0 and rec["roofline"]["frac"] > 0, name
+        assert 0 < rec["valu_roofline"]["algorithmic_frac"] < 1
+    p = line["pcie_inclusive"]
+    assert p["value"] < line["value"] and p["gbs_h2d"] > 10 and p["gbs_d2h"] > 10 and p["pageable_caller"]["value"] > 0
+
+
+def test_single_workload_line():
+    line = run_bench("--workload", "cfg5", "--steps", "10", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--no-pcie")
+    assert "configs[4]" in line["config"]["workload"] and "configs" not in line and "cpu_baseline" not in line
+    assert line["parity"]["ok"] is True and line["config"]["batch_per_gpu"] == 1 << 17
