@@ -36,7 +36,7 @@ VALU_MAD_PEAK = 1024 * 64 / 4.0 * 2.4e9    # measured: a wave64 v_mad_u64_u32 oc
 # mul = 16, GF(p^2) M = 48, S = 32 on the reference's real M/S counts), and the multiply-adds this implementation
 # EXECUTES per unit in radix 2^26 (M = 100, S = 50; DBL = 3M+4S = 500, ADD = 8M = 800; ladder step 1 300 x 64 endo,
 # 4 DBL + ADD = 2 800 x 62 windowed; table_endo 14 300; DH extras 8 600 (6 800 with the shared inversion); comb
-# 8 DBL + 35 mixed ADD (7M) = 28 500 + its share of an inversion): DESIGN.md section 5.
+# 6 DBL + 27 mixed ADD (7M) = 21 900 + its share of an inversion): DESIGN.md section 5.
 WORKLOADS = {
     "cfg2": dict(batch=1 << 16, steps=500, bytes=32 + 160 + 160, alg_mads=49_440, mads=97_600, seed=20002,
                  kernel="ladder_kernel<ENDO, FUSED>", unit="MUL_endo(m, P), variable base",
@@ -45,11 +45,11 @@ WORKLOADS = {
     "cfg3": dict(batch=1 << 20, steps=60, bytes=32 + 160, alg_mads=91_264, mads=173_600, seed=30002,
                  kernel="ladder_kernel<WINDOWED, LDS>", unit="MUL_windowed(m, G, table)",
                  text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
-    "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, mads=29_100 + 97_600 + 6_800, seed=40002,
+    "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, mads=22_500 + 97_600 + 6_800, seed=40002,
                  kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
                  unit="exchange = DH_endo(a, DH_endo(b, G)): two DH_core evaluations",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
-                      "(first half fixed-base through the 256-point comb of [392]G, same affine outputs as with table_endo([392]G); "
+                      "(first half fixed-base through the 1024-point comb of [392]G, same affine outputs as with table_endo([392]G); "
                       "second half variable-base); affine in/out"),
     "cfg5": dict(batch=1 << 17, steps=300, bytes=(192 + 352) // 2, alg_mads=(41_984 + 49_440) // 2, mads=(83_300 + 97_600) // 2, seed=50002,
                  kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer",
@@ -272,7 +272,7 @@ class Bench:
         elif workload == "cfg4":
             from fourq_amd import codec
             g392 = eng.mul_endo(codec.pack_scalars([392]), self.g1.reshape(1, 20))[0]      # curve4q.py:758
-            comb_h = eng.comb_table(g392)                                     # 256-point comb of [392]G (draft :725-729)
+            comb_h = eng.comb_table(g392)                                     # 1024-point comb of [392]G (draft :725-729)
             mid = torch.empty((n, 8), dtype=torch.int64, device=self.dev)
             out = torch.empty((n, 8), dtype=torch.int64, device=self.dev)
             st1 = torch.empty(n, dtype=torch.uint8, device=self.dev)

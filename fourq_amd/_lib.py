@@ -12,7 +12,7 @@ DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
 DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3
 
 MAX_BATCH = 0xFFFFFF00
-COMB_POINTS = 256 + 80               # FOURQ_COMB_POINTS: the fast comb and the one the constant-time mode scans
+COMB_POINTS = 1024 + 80              # FOURQ_COMB_POINTS: the fast comb and the one the constant-time mode scans
 COMB_WORDS = COMB_POINTS * 12        # FOURQ_COMB_WORDS
 BYTES_DECODE_BASE = 16
 

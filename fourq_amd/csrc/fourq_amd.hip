@@ -997,7 +997,9 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
     if (rc) return rc;
     size_t blocks = (n + BLOCK - 1) / BLOCK, blocks_max = c->lanes_w4 / BLOCK;
-    HIPRC_TRY(c, (c->ct ? ct_launch_comb : chain_launch_comb)((unsigned)(blocks < blocks_max ? blocks : blocks_max), c->stream, scalars, c->comb_limbs, out, status,
+    // constant-time mode: 256-lane blocks, four per CU, over the small shape; otherwise one block per CU with the fast shape's table
+    const unsigned grid_or_cus = c->ct ? (unsigned)(blocks < blocks_max ? blocks : blocks_max) : (unsigned)c->cus;
+    HIPRC_TRY(c, (c->ct ? ct_launch_comb : chain_launch_comb)(grid_or_cus, c->stream, scalars, c->comb_limbs, out, status,
                                                              group ? c->proj : nullptr, (u32)c->proj_capacity, (u32)n));
     if (group) HIPRC_TRY(c, chain_launch_normalize(group, c->stream, c->proj, (u32)c->proj_capacity, out, status, (u32)n));
     return FOURQ_OK;

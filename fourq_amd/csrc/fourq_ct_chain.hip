@@ -21,8 +21,9 @@ int ct_launch_lds(int algo, bool dh, unsigned grid, hipStream_t stream, const La
     return algo == ENDO ? launch_lds<ENDO>(dh, grid, stream, a) : launch_lds<WINDOWED>(dh, grid, stream, a);
 }
 int ct_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
-    if (proj) hipLaunchKernelGGL((comb_kernel<true, true>), dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
-    else hipLaunchKernelGGL((comb_kernel<false, true>), dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
+    constexpr size_t lds_bytes = (size_t)CombScan::POINTS * COMB_LDS_U32 * sizeof(u32);       // 11.25 KB: four blocks per CU
+    if (proj) hipLaunchKernelGGL((comb_kernel<true, true>), dim3(grid), dim3(BLOCK), lds_bytes, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
+    else hipLaunchKernelGGL((comb_kernel<false, true>), dim3(grid), dim3(BLOCK), lds_bytes, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
     return (int)hipGetLastError();
 }
 

@@ -702,23 +702,33 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 constexpr int COMB_POINTS = COMB_POINTS_ALL;                  // 256 (by address) + 80 (constant-time mode)
 static_assert(COMB_POINTS == FOURQ_COMB_POINTS, "include/fourq_amd.h and recode.hip.h disagree on the comb's shape");
 constexpr int COMB_ENTRY_U32 = 3 * COORD_U32;                 // (x+y, y-x, 2dxy)
-constexpr int COMB_LDS_U32 = COMB_ENTRY_U32;                  // stride in LDS (pads of 0, 4, 8, 12 dwords measured alike); 36 KB per block
+constexpr int COMB_LDS_U32 = COMB_ENTRY_U32;                  // stride in LDS (pads of 0, 4, 8, 12 dwords measured alike)
+constexpr int COMB_BLOCK_MAX = 1024;                          // the fast shape's table is 144 KB of LDS: ONE block per CU, up to 16 waves wide
+constexpr size_t COMB_FAST_LDS_BYTES = (size_t)CombFast::POINTS * COMB_LDS_U32 * sizeof(u32);
+static_assert(COMB_FAST_LDS_BYTES <= 160 * 1024, "the fast comb table must fit the CU's LDS");
 
 #if FQ_CHAIN   // only fourq_chain.hip launches it
-// [m]B, affine, from the comb: 8 doublings + 35 mixed additions per element
+// [m]B, affine, from the comb: 6 doublings + 27 mixed additions per element (constant-time mode: 9 + 49 on the small shape).
+// The block width is the launcher's choice (blockDim.x, a multiple of 64): the table is staged once per block.
 constexpr int COMB_MODE = FQ_SIGNED_LADDER ? 2 : 1;          // the comb's additions run on signed limbs like the LDS ladders
 template <bool DEFER, bool CT = false>
-__global__ __launch_bounds__(BLOCK, 4) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
+__global__ __launch_bounds__(CT ? BLOCK : COMB_BLOCK_MAX, CT ? 4 : 1) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
     using S = typename std::conditional<CT, CombScan, CombFast>::type;       // the constant-time mode scans the small sub-table
-    __shared__ __attribute__((aligned(16))) u32 lds[S::POINTS * COMB_LDS_U32];
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];                // S::POINTS * COMB_LDS_U32 dwords, sized by the launcher
     const u32* sub = comb_limbs + (CT ? CombFast::POINTS * COMB_ENTRY_U32 : 0);
-    for (int i = threadIdx.x; i < S::POINTS * COMB_ENTRY_U32; i += BLOCK)
-        lds[(i / COMB_ENTRY_U32) * COMB_LDS_U32 + (i % COMB_ENTRY_U32)] = sub[i];
+    const u32 width = blockDim.x;
+    if (COMB_LDS_U32 == COMB_ENTRY_U32) {
+        for (u32 i = threadIdx.x; i < (u32)(S::POINTS * COMB_ENTRY_U32 / 4); i += width)
+            reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(sub)[i];
+    } else {
+        for (u32 i = threadIdx.x; i < (u32)(S::POINTS * COMB_ENTRY_U32); i += width)
+            lds[(i / COMB_ENTRY_U32) * COMB_LDS_U32 + (i % COMB_ENTRY_U32)] = sub[i];
+    }
     __syncthreads();
-    const u32 lanes = gridDim.x * BLOCK;
-    const u32 n_round = (n + BLOCK - 1) / BLOCK * BLOCK;
+    const u32 lanes = gridDim.x * width;
+    const u32 n_round = (n + width - 1) / width * width;
 #pragma unroll 1
-    for (u32 it = blockIdx.x * BLOCK + threadIdx.x; it < n_round; it += lanes) {
+    for (u32 it = blockIdx.x * width + threadIdx.x; it < n_round; it += lanes) {
         const bool live = it < n;
         const u32 id = live ? it : n - 1;
         u64 m[4];

@@ -158,10 +158,11 @@ FQ_DEV u32 win_top_code(const WinScalar& w) {        // digit 62 = (r >> 252) | 
     return (1u << 3) | (((d - 1) >> 1) & 7);
 }
 
-// ---- fixed-base comb: mLSB-set recoding, w = 7, v = 4, e = 9, d = 36 (and 5, 5, 10, 50) --
-// Shape chosen by the multiply-add count (e - 1) * 500 + (v * e - 1) * 700 under the LDS budget of four blocks per CU
-// (v * 2^(w-1) points of 144 bytes): (7, 4) = 8 doublings + 35 mixed additions = 28 500, 256 points; round 1's (5, 5) =
-// 9 + 49 = 38 800 with 80 points; (6, 5) 34 800; (8, 2) 29 200; anything cheaper needs more than 300 points.
+// ---- fixed-base comb: mLSB-set recoding, w = 9, v = 4, e = 7, d = 28 (and 5, 5, 10, 50) --
+// Shape chosen by the multiply-add count (e - 1) * 500 + (v * e - 1) * 700 under the CU's 160 KB of LDS held by ONE block of up
+// to 1 024 lanes (v * 2^(w-1) points of 144 bytes): (9, 4, 7) = 6 doublings + 27 mixed additions = 21 900 with 1 024 points
+// (144 KB); (10, 2, 13) 23 500; (8, 4, 8) 25 200 with 512 points; the earlier four-blocks-per-CU shape (7, 4, 9) 28 500 with
+// 256 points; round 1's (5, 5, 10) 38 800 with 80 points.
 // (Faz-Hernandez, Longa, Sanchez: the method the draft points to for multiplications by the generator,
 // draft-ladd-cfrg-4q.md:725-729.)  For odd k < 2^250:  k = sum_{i<250} b_i 2^i with b_i in {+-1} for i < d and
 // b_i in {0, b_{i mod d}} above.  Column i (0 <= i < d) carries the sign b_i and the (w-1)-bit index
@@ -172,11 +173,12 @@ template <int W_, int V_, int E_> struct CombShape {
     static constexpr int W = W_, V = V_, E = E_, D = V_ * E_, BLOCK_POINTS = 1 << (W_ - 1), POINTS = V_ << (W_ - 1);
     static_assert(W_ * V_ * E_ >= 250 && V_ * E_ <= 64, "comb shape");
 };
-typedef CombShape<7, 4, 9> CombFast;       // 256 points: 8 doublings + 35 mixed additions
+typedef CombShape<9, 4, 7> CombFast;       // 1 024 points: 6 doublings + 27 mixed additions
 typedef CombShape<5, 5, 10> CombScan;      // 80 points: 9 doublings + 49 mixed additions, 16-entry blocks
 constexpr int COMB_POINTS_ALL = CombFast::POINTS + CombScan::POINTS;       // the table object: fast points first
 template <typename S> struct CombDigits {
-    u64 plane[S::W];     // plane[0] bit i: b_i == +1 ; plane[r] bit i: |b_{r d + i}|
+    typedef typename std::conditional<(S::D <= 32), u32, u64>::type plane_t;      // d bits per plane: one register when they fit
+    plane_t plane[S::W];     // plane[0] bit i: b_i == +1 ; plane[r] bit i: |b_{r d + i}|
     u32 negate;          // ~0 when the scalar was replaced by N - k (even k): the result is negated
 };
 template <typename S> FQ_DEV CombDigits<S> comb_recode(const u64 m[4]) {
@@ -204,17 +206,18 @@ template <typename S> FQ_DEV CombDigits<S> comb_recode(const u64 m[4]) {
     for (int i = 0; i < 4; i++) k[i] = was_even ? alt[i] : k[i];        // odd, in [1, N]
     const u64 mask_d = (1ull << COMB_D) - 1;
     const u64 sign = ((k[0] >> 1) & (mask_d >> 1)) | (1ull << (COMB_D - 1));     // b_i = +1  <=>  bit set
-    c.plane[0] = sign;
+    typedef typename CombDigits<S>::plane_t plane_t;
+    c.plane[0] = (plane_t)sign;
     // carry word c = k >> d
     u64 c0 = (k[0] >> COMB_D) | (k[1] << (64 - COMB_D)), c1 = (k[1] >> COMB_D) | (k[2] << (64 - COMB_D));
     u64 c2 = (k[2] >> COMB_D) | (k[3] << (64 - COMB_D)), c3 = k[3] >> COMB_D;
 #pragma unroll 1
     for (int r = 1; r < COMB_W; r++) {
-        u64 pl = 0;
+        plane_t pl = 0;
 #pragma unroll 1
         for (int i = 0; i < COMB_D; i++) {
             u64 bit = c0 & 1;
-            pl |= bit << i;
+            pl |= (plane_t)bit << i;
             u64 inc = bit & ~(sign >> i) & 1;          // b = -1  ->  c = (c >> 1) + 1
             c0 = (c0 >> 1) | (c1 << 63); c1 = (c1 >> 1) | (c2 << 63); c2 = (c2 >> 1) | (c3 << 63); c3 >>= 1;
             u64 s0 = c0 + inc; u64 cy = s0 < inc; c0 = s0;

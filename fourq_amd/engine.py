@@ -226,7 +226,7 @@ class Engine:
         t = None if table392_host is None else _host(table392_host, None).ravel()
         self._ck(self._lib.fourq_dh_exchange_batch_dev(self._ctx, _ptr(a_scalars), _ptr(b_scalars), _ptr(base), _ptr(t), _ptr(out_affine), _ptr(status), n))
 
-    # ---- fixed-base comb (256-point table; affine outputs only) -----------------------------------
+    # ---- fixed-base comb (1024-point table; affine outputs only) -----------------------------------
     def comb_table(self, p_r1):
         """Comb table (_lib.COMB_WORDS words) of the order-N point `p_r1` (fourq_comb_table)."""
         p = _host(p_r1, None).ravel()

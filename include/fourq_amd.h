@@ -186,14 +186,14 @@ int fourq_encode_batch_dev(fourq_ctx *ctx, const uint64_t *points_affine, uint8_
 int fourq_decode_batch_dev(fourq_ctx *ctx, const uint8_t *in32, uint64_t *out_affine, uint8_t *status, size_t n);
 
 /* ---- fixed-base comb (draft-ladd-cfrg-4q.md:725-729: "MAY use any method ... provided that it agrees") ------
- * A comb table (mLSB-set recoding, w = 7, v = 4: 256 points) for a base point B of order N makes [m]B cost 8 doublings + 35
- * mixed additions instead of 64 + 64; the table object also holds an 80-point comb (w = v = 5) that the constant-time
- * mode scans in 16-entry blocks.  Outputs are canonical AFFINE points, identical to
+ * A comb table (mLSB-set recoding, w = 9, v = 4: 1 024 points, held in one CU's LDS) for a base point B of order N makes [m]B
+ * cost 6 doublings + 27 mixed additions instead of 64 + 64; the table object also holds an 80-point comb (w = v = 5) that the
+ * constant-time mode scans in 16-entry blocks.  Outputs are canonical AFFINE points, identical to
  * R1toAffine(MUL_endo(m, B)); the un-normalised R1 tuple of the reference is NOT reproduced, so this serves the
  * DH/keygen side (DH_endo(m, G, table) == fourq_comb_mul_batch with the comb of [392]G), not raw MUL_*.
- * comb table: FOURQ_COMB_WORDS words = 256 + 80 entries x (x+y, y-x, 2d*x*y), 4 words each (31.5 KiB). */
-#define FOURQ_COMB_POINTS 336
-#define FOURQ_COMB_WORDS (336 * 12)
+ * comb table: FOURQ_COMB_WORDS words = 1 024 + 80 entries x (x+y, y-x, 2d*x*y), 4 words each (103.5 KiB). */
+#define FOURQ_COMB_POINTS 1104
+#define FOURQ_COMB_WORDS (1104 * 12)
 int fourq_comb_table(fourq_ctx *ctx, const uint64_t *p_r1, uint64_t *comb);
 /* status[i]: FOURQ_DH_OK or FOURQ_DH_NEUTRAL ([m]B is the neutral point); out zeroed in that case */
 int fourq_comb_mul_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *comb, uint64_t *out_affine, uint8_t *status, size_t n);

@@ -1,4 +1,4 @@
-"""Fixed-base comb: affine [m]B from a 256-point table (w = 7, v = 4, e = 9, d = 36; the constant-time mode scans
+"""Fixed-base comb: affine [m]B from a 1 024-point table (w = 9, v = 4, e = 7, d = 28; the constant-time mode scans
 an 80-point comb, w = v = 5, kept in the same table object).  Parity is at the affine level
 (the draft's "MAY use any method ... provided that it agrees", draft-ladd-cfrg-4q.md:725-729): outputs must
 equal R1toAffine(MUL_endo(m, B)) and, for B = [392]G, DH_endo(m, G)."""
@@ -24,8 +24,9 @@ def seeded_scalars(seed, n):
 def test_comb_table_entries(eng):
     from fourq_amd import _lib
     comb = eng.comb_table(codec.pack_point(G1)).reshape(_lib.COMB_POINTS, 12)
-    for t in (0, 1, 63, 64, 101, 191, 255, 256, 257, 272, 300, 335):       # both shapes of the table object
-        (W, V, E, D), s = ((7, 4, 9, 36), t) if t < 256 else ((5, 5, 10, 50), t - 256)
+    assert _lib.COMB_POINTS == 1024 + 80
+    for t in (0, 1, 255, 256, 401, 767, 1023, 1024, 1025, 1040, 1068, 1103):       # both shapes of the table object
+        (W, V, E, D), s = ((9, 4, 7, 28), t) if t < 1024 else ((5, 5, 10, 50), t - 1024)
         j, u = s >> (W - 1), s & ((1 << (W - 1)) - 1)
         m = (1 << (E * j)) * (1 + sum(((u >> r) & 1) << (D * (r + 1)) for r in range(W - 1)))
         x, y = o.R1toAffine(o.MUL_endo(m % o.N, G1))
@@ -37,7 +38,7 @@ def test_comb_equals_mul_endo_affine(eng):
     rng = random.Random(77)
     B = o.MUL_endo(rng.getrandbits(256), G1)                    # a projective base point of order N
     comb = eng.comb_table(codec.pack_point(B))
-    ms = [0, 1, 2, 3, o.N - 1, o.N, o.N + 1, 2 * o.N, (1 << 256) - 1, 1 << 255, 1 << 36, (1 << 36) - 1, 1 << 50, (1 << 50) - 1, 1 << 216, (1 << 245) + 1] + [rng.getrandbits(256) for _ in range(40)]
+    ms = [0, 1, 2, 3, o.N - 1, o.N, o.N + 1, 2 * o.N, (1 << 256) - 1, 1 << 255, 1 << 28, (1 << 28) - 1, 1 << 36, (1 << 36) - 1, 1 << 50, (1 << 50) - 1, (1 << 252) - 1, 1 << 216, (1 << 245) + 1] + [rng.getrandbits(256) for _ in range(40)]
     out, st = eng.comb_mul(codec.pack_scalars(ms), comb)
     for m, got, s in zip(ms, out, st):
         want = o.R1toAffine(o.MUL_endo(m, B))
@@ -63,7 +64,7 @@ def test_comb_keygen_equals_dh_fixed_base_full_batch(eng):
     assert not wst.any() and np.array_equal(got[:k], want)
 
 
-@pytest.mark.parametrize("n", [1, 255, 257])
+@pytest.mark.parametrize("n", [1, 63, 65, 255, 257, 16385, 70001])      # block widths 64 ... 512, ragged tails
 def test_comb_ragged(eng, n):
     s = seeded_scalars(900 + n, n)
     comb = eng.comb_table(codec.pack_point(G1))
