@@ -237,6 +237,51 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo(const R1& P, u32*
     }
 }
 
+// The same table with its slot traffic reordered (prep_kernel): on gfx950 loads and stores retire through one in-order counter,
+// so a load issued after a store waits for that store to drain to L2 as well (microseconds when 64 lanes scatter 16 bytes each to
+// their own lines).  build_table_endo above reads back ten times right behind its own stores.  Here every read-back is issued
+// BEFORE the stores of the stretch it belongs to: the base T[0] and the next step's working point ahead of this step's parking /
+// result stores, the base T[m+1] ahead of the store of T[half+m]; step 0 takes P from registers.  Same values, same table.
+#ifndef FQ_PREP_PIPELINED
+#define FQ_PREP_PIPELINED 1
+#endif
+template <typename L = LimbSlots> FQ_DEV void build_table_endo_pipelined(const R1& P, u32* slot) {
+    constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
+    static_assert(SLOT_Q > SLOT_P && SLOT_Q + 30 <= L::SLOT, "this builder parks two points in the slot");
+    store_r2<L>(slot, r1_to_r2(P));
+    Fe2<1> X = P.X, Y = P.Y, Z = P.Z;
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        Proj<1, 2, 1> t;
+        if (step == 1) {                 // tau(P), parked by step 0 (phi and psi share it, curve4q.py:318-322)
+            t.X = X; t.Y = widen<2>(Y); t.Z = Z;
+        } else {
+            t = tau(X, Y, Z);
+            if (step == 0) store_xyz(slot + SLOT_P, t.X, fe2_carry(t.Y), t.Z);
+        }
+        Proj<2, 2, 2> u;
+        if (step == 0) {
+            u = upsilon(t);
+        } else {
+            Proj<1, 1, 1> c = chi(t);
+            u.X = widen<2>(c.X); u.Y = widen<2>(c.Y); u.Z = widen<2>(c.Z);
+        }
+        R1 V = tau_dual(u.X, u.Y, u.Z);
+        R2 base = load_r2<L>(slot);                                              // T[0]: behind stores that drained an endomorphism ago
+        if (step < 2) load_xyz(slot + (step == 0 ? SLOT_P : SLOT_Q), X, Y, Z);   // next step's input; step 1 reads the Q parked by step 0
+        if (step == 0) store_xyz(slot + SLOT_Q, V.X, V.Y, V.Z);
+        R3 V3 = r1_to_r3(V);
+        const int half = 1 << step;
+#pragma unroll 1
+        for (int m = 0; m < half; m++) {
+            R2 next = base;
+            if (m + 1 < half) next = load_r2<L>(slot + (m + 1) * L::ENTRY);      // ahead of this iteration's store
+            store_r2<L>(slot + (half + m) * L::ENTRY, r1_to_r2(add_core(V3, as_signed(base))));
+            base = next;
+        }
+    }
+}
+
 // ---- the ladders -------------------------------------------------------------------------------
 // The fused MUL_endo kernel runs one wave per SIMD: its ladder uses the chained products only together with
 // register-preloaded table entries (gathers issued a whole doubling ahead); measured 0.416 ms per 2^16 batch
@@ -270,6 +315,23 @@ template <int ALGO, int SRC, bool DH> constexpr bool signed_ladder() {
 #ifndef FQ_FUSED_LADDER_CHAIN
 #define FQ_FUSED_LADDER_CHAIN 1
 #endif
+// FQ_PREBUILT_TOUCH: the two-kernel route's ladder reads a lane's table entry (one 128-byte line of its scratch slot) inside the
+// addition, with no registers to spare for issuing the eight loads a doubling ahead (128-VGPR budget).  A one-dword load of the
+// line at the top of the step, result unused, starts the HBM / Infinity-Cache fetch early: the real loads then hit L2.
+// Same-box A/B (profiles/r02_split_route.txt): cfg5 +2.2 % (two waves per SIMD), cfg4 +0..1 % (four waves hide the latency themselves).
+#ifndef FQ_PREBUILT_TOUCH
+#define FQ_PREBUILT_TOUCH 1
+#endif
+// The load lands in its register whenever the memory system answers, and hipcc does not track loads issued from asm: the register
+// must stay reserved until a wait the compiler does track has covered it.  touch_done() after the addition does that: loads return
+// in order, so once the addition's own (younger) loads have been waited for, this one has landed.  `after` is a limb of the sum's X,
+// which depends on all four coordinates of the entry: tying it to the same statement keeps hipcc from moving the release up.
+template <typename TP> FQ_DEV u32 touch_line(const TP* p) {
+    u32 landing;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(landing) : "v"(p) : "memory");
+    return landing;
+}
+FQ_DEV void touch_done(u32 landing, u32& after) { asm volatile("" : "+v"(after) : "v"(landing) : "memory"); }
 // a ladder on signed limbs (CH == 2) hands its result back with non-negative limbs
 template <int CH> FQ_DEV R1 ladder_result(const R1& Q) {
     if constexpr (CH == 2) {
@@ -281,7 +343,7 @@ template <int CH> FQ_DEV R1 ladder_result(const R1& Q) {
         return Q;
     }
 }
-template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:436-442
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, bool TOUCH = false, typename TP> FQ_DEV R1 ladder_endo(const EndoDigits& e, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:436-442
     Proj<1, 1, 1> q4 = start_table<L>(tbl + (e.top & 7) * stride, 0u);        // s[64] = 1: the entry itself
     if constexpr (EF::ON) q4.Z = ef.get(e.top & 7, 0);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
@@ -295,13 +357,16 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
             Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_entry<CH>(Q, t, neg);
         } else {
+            u32 landing = 0;
+            if (TOUCH) landing = touch_line(entry);
             Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_table<CH, L>(Q, entry, endo_neg_mask(e, i));
+            if (TOUCH) touch_done(landing, Q.X.re.l[0]);
         }
     }
     return ladder_result<CH>(Q);
 }
-template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:228-235
+template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, bool TOUCH = false, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
     Proj<1, 1, 1> q4 = start_table<L>(tbl + (code & 7) * stride, (code >> 3) - 1u);
     if constexpr (EF::ON) q4.Z = ef.get(code & 7, 0);
@@ -317,9 +382,12 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
             for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_entry<CH>(Q, t, neg);
         } else {
+            u32 landing = 0;
+            if (TOUCH) landing = touch_line(entry);
 #pragma unroll 1
             for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
             Q = add_table<CH, L>(Q, entry, neg);
+            if (TOUCH) touch_done(landing, Q.X.re.l[0]);
         }
     }
     return ladder_result<CH>(Q);
@@ -553,7 +621,7 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
         ef.lane = reinterpret_cast<uint2*>(lds_mem) + threadIdx.x;
         build_table_endo_lds<PrebuiltSlots, LdsEF, true>(P, slot, ef);
     } else if (ALGO == ENDO) {
-        build_table_endo<PrebuiltSlots>(P, slot);
+        if (FQ_PREP_PIPELINED) build_table_endo_pipelined<PrebuiltSlots>(P, slot); else build_table_endo<PrebuiltSlots>(P, slot);
     } else {
         build_table_windowed<PrebuiltSlots>(P, slot);
     }
@@ -588,7 +656,11 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
         using L = typename std::conditional<SRC == PREBUILT, PrebuiltSlots, typename std::conditional<USE_EF, NDSlots, FusedSlots>::type>::type;
+#ifdef FQ_DIAG_SAME_SLOT    // timing diagnostic only (results wrong): every lane of the two-kernel route's ladder reads slot 0, i.e. no table traffic
+        u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : 0) * L::SLOT;
+#else
         u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * L::SLOT;
+#endif
         const u32* tbl = slot;
         if (SRC == PREBUILT && a.slot_of) {                              // mixed batch: own table or the shared one
             const u32 own = a.slot_of[pos];
@@ -648,7 +720,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
                 static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
                 Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else
-            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(e, tbl, L::ENTRY, ef);
+            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L, EF, SRC == PREBUILT && FQ_PREBUILT_TOUCH>(e, tbl, L::ENTRY, ef);
         } else {
             WinScalar w = win_reduce(m);
             constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
@@ -665,7 +737,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
                 static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
                 Q = ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else
-            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L>(w, tbl, L::ENTRY, ef);
+            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L, EF, SRC == PREBUILT && FQ_PREBUILT_TOUCH>(w, tbl, L::ENTRY, ef);
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
             if (live) {
