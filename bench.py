@@ -338,7 +338,8 @@ class Bench:
             "value": round(total / elapsed, 1), "unit": "scalar-mults/s" if workload != "cfg4" else "exchanges/s",
             "ms_per_step": round(1e3 * elapsed / steps, 4),
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic(workload),
+                         "frac": round(ach_gbs / HBM_PEAK_GBS, 6),
+                         "traffic": None if self.eng.ct_select else _pmc_traffic(workload),     # the PMC passes ran on the default kernels
                          "kernel": wl["kernel"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n,
                          "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
             "valu_roofline": {

@@ -37,7 +37,8 @@ traffic_path = os.path.join(dst, "pmc_traffic.json")
 per_workload = {}
 for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
     w = os.path.basename(wdir)
-    stats = glob.glob(os.path.join(wdir, "trace", "*", "*_kernel_stats.csv"))
+    # gpurun merges a call's files INTO gpurun_out/: a tag used twice leaves two runs side by side -- take the newest of each kind
+    stats = sorted(glob.glob(os.path.join(wdir, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
     if not stats:
         continue
     shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, w)))
@@ -53,7 +54,7 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
                                      "launches_per_step": round(int(r["Calls"]) / steps_traced, 3) if steps_traced else None,
                                      "share_of_gpu_time_pct": float(r["Percentage"]), "counters": {}}
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-        files = glob.glob(os.path.join(wdir, sub, "*", "*_counter_collection.csv"))
+        files = sorted(glob.glob(os.path.join(wdir, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
         if not files:
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
