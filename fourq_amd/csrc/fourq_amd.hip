@@ -746,6 +746,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
                 hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess) rc = FOURQ_ERR_HIP;
         }
         if (rc) break;
+        if (chain_setup_device() != 0) { rc = FOURQ_ERR_HIP; break; }
         // resident blocks per CU of the fused variable-base kernels (they own the per-lane scratch slots)
         int occ = 8, o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<ENDO, FUSED, false>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;

@@ -38,14 +38,18 @@ int chain_launch_prep(int algo, bool dh, unsigned grid, hipStream_t stream, cons
     }
     return (int)hipGetLastError();
 }
+// The comb's table needs more dynamic LDS than the 64 KB a kernel gets by default: raised once per device, at context creation
+// (a launch then only enqueues, so the _dev entry points stay capturable into a graph).
+int chain_setup_device() {
+    hipError_t e = hipFuncSetAttribute((const void*)comb_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COMB_FAST_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)comb_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COMB_FAST_LDS_BYTES);
+    return (int)e;
+}
 // One block per CU holds the whole 144 KB table; its width follows the batch so that a small batch still reaches every CU.
 int chain_launch_comb(unsigned cus, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
     unsigned width = 64;
     while (width < (unsigned)COMB_BLOCK_MAX && (size_t)width * cus < n) width *= 2;
     const unsigned blocks = (n + width - 1) / width, grid = blocks < cus ? blocks : cus;
-    const void* fn = proj ? (const void*)comb_kernel<true> : (const void*)comb_kernel<false>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)COMB_FAST_LDS_BYTES);   // above the 64 KB default
-    if (e != hipSuccess) return (int)e;
     if (proj) hipLaunchKernelGGL(comb_kernel<true>, dim3(grid), dim3(width), COMB_FAST_LDS_BYTES, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
     else hipLaunchKernelGGL(comb_kernel<false>, dim3(grid), dim3(width), COMB_FAST_LDS_BYTES, stream, scalars, comb_limbs, out, status, proj, proj_stride, n);
     return (int)hipGetLastError();

@@ -917,6 +917,7 @@ __global__ __launch_bounds__(BLOCK) void normalize_kernel(const uint4* proj, u32
 // launchers implemented in fourq_chain.hip (FQ_CHAIN=1 code objects)
 int chain_launch_ladder(int algo, int src, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int chain_launch_prep(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int chain_setup_device();       // per-device function attributes (the comb's dynamic LDS); called by fourq_ctx_create
 int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n);
 int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
 // constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)

@@ -73,3 +73,40 @@ def test_comb_ragged(eng, n):
     full = oc.mul(oc.ENDO, s, None, te)
     want = eng.prim("PT_R1TOAFFINE", full)
     assert not st.any() and np.array_equal(got, want)
+
+
+def test_comb_keygen_then_dh_in_a_hip_graph(eng):
+    """Key generation through the comb followed by the peer's variable-base DH on the keys, captured into one HIP graph and
+    replayed: the comb's 144 KB of dynamic LDS is granted at context creation, so the launch itself is a pure enqueue."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 5000
+    b_h, a_h = seeded_scalars(71, n), seeded_scalars(72, n)
+    comb = eng.comb_table(codec.pack_point(o.MUL_endo(392, G1)))
+    b, a = (torch.from_numpy(x.view(np.int64)).to(dev) for x in (b_h, a_h))
+    keys = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    shared = torch.empty((n, 8), dtype=torch.int64, device=dev)
+    st1 = torch.empty(n, dtype=torch.uint8, device=dev)
+    st2 = torch.empty(n, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    eng.set_stream(side.cuda_stream)
+    try:
+        eng.comb_mul_dev(b, comb, keys, st1, n)            # stages the comb and sizes the context's buffers outside the capture
+        eng.dh_endo_dev(a, keys, None, shared, st2, n)
+        eng.sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            eng.comb_mul_dev(b, comb, keys, st1, n)
+            eng.dh_endo_dev(a, keys, None, shared, st2, n)
+            graph.capture_end()
+        keys.zero_(); shared.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        eng.set_stream(None)
+    gaff = np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0)
+    want_keys, wst = oc.dh(oc.ENDO, b_h, gaff)
+    assert not wst.any() and not st1.cpu().numpy().any() and np.array_equal(keys.cpu().numpy().view(np.uint64), want_keys)
+    want_shared, wst2 = oc.dh(oc.ENDO, a_h, want_keys)
+    assert not wst2.any() and not st2.cpu().numpy().any() and np.array_equal(shared.cpu().numpy().view(np.uint64), want_shared)
