@@ -360,6 +360,41 @@ class Bench:
         return {"gate": "every output of the shard bit-exact vs oracle/fourq_oracle.c", "ok": True, "units": int(len(got)),
                 "c_oracle_units_per_s": round(rate, 1), "c_oracle_threads": threads}, got, want
 
+    def alongside(self, workload, d, steps):
+        """cfg2 reports MUL_windowed on the same inputs alongside MUL_endo, cfg3 reports MUL_endo(m, G, table)
+        alongside MUL_windowed.  Same timing discipline (HIP events on the launch stream around back-to-back steps), every
+        output compared with the C oracle; multiply-add counts as in WORKLOADS."""
+        import numpy as np
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c as oc
+        eng, n = self.eng, len(d["scalars_h"])
+        scalars = d["keep"][0]
+        out = torch.empty((n, 20), dtype=torch.int64, device=self.dev)
+        if workload == "cfg2":
+            points = self.to_dev(d["points_h"])
+            name, alg, mads = "MUL_windowed(m, P), variable base, same scalars and points", 94_992, 181_000
+            step = lambda: eng.mul_windowed_dev(scalars, points, out, n)
+            want = lambda: oc.mul(oc.WINDOWED, d["scalars_h"], d["points_h"])
+        else:
+            name, alg, mads = "MUL_endo(m, G, table), fixed base, same scalars", 41_984, 83_300
+            step = lambda: eng.mul_endo_fixed_dev(scalars, self.table_g, out, n)
+            want = lambda: oc.mul(oc.ENDO, d["scalars_h"], None, self.table_g)
+        for _ in range(max(2, steps // 10)):
+            step()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record(self.stream)
+        for _ in range(steps):
+            step()
+        ev1.record(self.stream)
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / steps
+        if not np.array_equal(out.cpu().numpy().view(np.uint64), want()):
+            raise SystemExit("PARITY FAILURE: alongside op of %s differs from the C oracle" % workload)
+        return {"op": name, "batch_per_gpu": n, "steps": steps, "ms_per_step": round(ms, 4), "value_per_gpu": round(n / (ms * 1e-3), 1), "unit": "scalar-mults/s",
+                "parity_ok": True, "algorithmic_frac": round(alg * n / (ms * 1e-3) / VALU_MAD_PEAK, 4), "executed_frac": round(mads * n / (ms * 1e-3) / VALU_MAD_PEAK, 4)}
+
     def gather_ms(self, out, n, reps=3):
         """The path's only collective: results gathered to rank 0 (RCCL over xGMI; gloo in rehearsals).  Median of `reps`."""
         import torch
@@ -463,6 +498,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the pure-Python CPU baseline leg (rank 0)")
     ap.add_argument("--no-configs", action="store_true", help="headline only: skip the nested cfg3/cfg4/cfg5 records")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive host-array measurement")
+    ap.add_argument("--no-alongside", action="store_true", help="skip the second operation SURVEY.md 8(d) reports alongside cfg2 / cfg3")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the whole-shard C-oracle gate")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -495,6 +531,9 @@ def main():
     rec, d = b.run(args.workload, n, steps, args.warmup)
     parity, got, want = ({"gate": "skipped (--no-parity)", "ok": None}, None, None) if args.no_parity else b.parity_gate(args.workload, d)
     gather = b.gather_ms(d["out"], n) if world > 1 else None
+    alongside = None
+    if rank == 0 and args.workload in ("cfg2", "cfg3") and not args.no_alongside and not args.no_parity:
+        alongside = b.alongside(args.workload, d, steps=100 if args.workload == "cfg2" else 20)
 
     configs = {}
     others = [] if (args.no_configs or args.batch) else [w for w in sorted(WORKLOADS) if w != args.workload]
@@ -508,6 +547,8 @@ def main():
             r["gather_ms"] = b.gather_ms(dw["out"], WORKLOADS[w]["batch"])
         if world == 1 and w == "cfg3" and not args.no_pcie and want_w is not None:
             r["pcie_inclusive"] = b.pcie_inclusive("cfg3", dw, want_w, reps=3)
+        if rank == 0 and w == "cfg3" and not args.no_alongside and not args.no_parity:
+            r["alongside"] = b.alongside("cfg3", dw, steps=20)
         configs[w] = r
         del dw
         torch.cuda.empty_cache()
@@ -532,6 +573,8 @@ def main():
         if gather is not None:
             line["gather_ms"] = gather
             line["config"]["gather"] = "results of all ranks gathered to rank 0 (fourq_amd.dist.gather_rows), untimed in `value`, median of 3"
+        if alongside is not None:
+            line["alongside"] = alongside
         if configs:
             line["configs"] = configs
         if world == 1 and not args.no_pcie and want is not None and args.workload in ("cfg2", "cfg3"):

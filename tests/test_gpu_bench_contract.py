@@ -28,7 +28,7 @@ def test_default_line_has_the_contract_keys():
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("valu_roofline", dict), ("parity", dict),
-                     ("configs", dict), ("pcie_inclusive", dict)):
+                     ("configs", dict), ("pcie_inclusive", dict), ("alongside", dict)):
         assert isinstance(line[key], typ), key
     assert line["vs_baseline"] is None and line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 2
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic" and line["dtype"] == "u64"
@@ -48,11 +48,13 @@ def test_default_line_has_the_contract_keys():
     for name, rec in line["configs"].items():
         assert rec["parity"]["ok"] is True and rec["ms_per_step"] > 0 and rec["roofline"]["frac"] > 0, name
         assert 0 < rec["valu_roofline"]["algorithmic_frac"] < 1
+    for rec, op in ((line["alongside"], "MUL_windowed"), (line["configs"]["cfg3"]["alongside"], "MUL_endo")):   # the other ladder, reported alongside
+        assert rec["op"].startswith(op) and rec["parity_ok"] is True and rec["ms_per_step"] > 0 and 0 < rec["algorithmic_frac"] < rec["executed_frac"] < 1
     p = line["pcie_inclusive"]
     assert p["value"] < line["value"] and p["gbs_h2d"] > 10 and p["gbs_d2h"] > 10 and p["pageable_caller"]["value"] > 0
 
 
 def test_single_workload_line():
     line = run_bench("--workload", "cfg5", "--steps", "10", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--no-pcie")
-    assert "configs[4]" in line["config"]["workload"] and "configs" not in line and "cpu_baseline" not in line
+    assert "configs[4]" in line["config"]["workload"] and "configs" not in line and "cpu_baseline" not in line and "alongside" not in line
     assert line["parity"]["ok"] is True and line["config"]["batch_per_gpu"] == 1 << 17

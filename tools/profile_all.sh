@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 for w in $W; do
   OUT=$ROOTDIR/gpurun_out/$TAG/$w
   mkdir -p $OUT
-  ARGS="--workload $w --no-configs --no-cpu-baseline --no-pcie"
+  ARGS="--workload $w --no-configs --no-cpu-baseline --no-pcie --no-alongside"
   python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
   echo "$w: $(python3 -c "import json;l=json.load(open('$OUT/bench.json'));print(l['value'], l['unit'], l['ms_per_step'], 'ms/step')")"
   cd /tmp
