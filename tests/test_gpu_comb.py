@@ -64,7 +64,7 @@ def test_comb_keygen_equals_dh_fixed_base_full_batch(eng):
     assert not wst.any() and np.array_equal(got[:k], want)
 
 
-@pytest.mark.parametrize("n", [1, 63, 65, 255, 257, 16385, 70001])      # block widths 64 ... 512, ragged tails
+@pytest.mark.parametrize("n", [1, 63, 65, 255, 257, 16385, 40000, 70001])      # block widths 64, 128, 256, 512 (1 024: the 2^18 test), ragged tails
 def test_comb_ragged(eng, n):
     s = seeded_scalars(900 + n, n)
     comb = eng.comb_table(codec.pack_point(G1))
