@@ -9,4 +9,4 @@ from . import codec, constants  # noqa: F401
 from ._lib import FourQError  # noqa: F401
 from .engine import Engine, default_engine  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

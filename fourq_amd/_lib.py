@@ -12,6 +12,7 @@ DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
 DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3
 
 MAX_BATCH = 0xFFFFFF00
+ABI_VERSION = 200                    # fourq_version(): 0.2.0 (round 2: protocol calls, host pipeline, 1 104-point comb table object)
 COMB_POINTS = 1024 + 80              # FOURQ_COMB_POINTS: the fast comb and the one the constant-time mode scans
 COMB_WORDS = COMB_POINTS * 12        # FOURQ_COMB_WORDS
 BYTES_DECODE_BASE = 16
@@ -123,6 +124,9 @@ def load():
         fn = getattr(lib, name)   # AttributeError here = header / library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.fourq_version() != ABI_VERSION:       # e.g. a library built before the comb table grew: its buffers would not match ours
+        raise FourQError("%s is version %d, this package expects %d: rebuild it (`python -m fourq_amd.build --force`)"
+                         % (LIB_PATH, lib.fourq_version(), ABI_VERSION))
     _lib = lib
     return lib
 

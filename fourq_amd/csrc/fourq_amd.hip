@@ -707,7 +707,7 @@ extern "C" {
 
 #define FQ_API __attribute__((visibility("default")))
 
-FQ_API int fourq_version(void) { return 100; }
+FQ_API int fourq_version(void) { return 200; }    // 0.2.0; fourq_amd/_lib.py checks it at load time
 
 FQ_API const char* fourq_strerror(int code) {
     switch (code) {
