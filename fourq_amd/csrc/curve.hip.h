@@ -472,9 +472,20 @@ template <int CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_m
 // Q + (+-A) for a precomputed AFFINE point A = (x+y, y-x, 2d*x*y) read from `entry` (three coordinates of
 // COORD_U32 dwords): ADD_core with the table point's 2Z = 2, i.e. D = 2*Z1 costs no multiplication.  Used by
 // the fixed-base comb, not by the reference-shaped MUL_* paths.
+// an opaque copy of every limb: the value is (re)defined in the current basic block as a 32-bit register
+template <int B> FQ_DEV void fe2_here(Fe2<B>& x) {
+#pragma unroll
+    for (int i = 0; i < 5; i++) { FQ_SIGN_UNKNOWN(x.re.l[i]); FQ_SIGN_UNKNOWN(x.im.l[i]); }
+}
 template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_affine_table(const R1& q, const P* entry, u32 neg_mask) {
     const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
-    Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
+    // In the comb's loop Q reaches this addition through a join (the doubling is conditional), and hipcc sign-extends the limbs
+    // of Ta and Tb on the far side of it: instruction selection, which works block by block, then sees 64-bit operands and
+    // expands each of 90 products into v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3_u32.  Opaque copies keep the limbs 32-bit here.
+    Fe2<4> Ta = q.Ta;
+    Fe2<2> Tb = q.Tb;
+    if constexpr (CH == 2) { fe2_here(Ta); fe2_here(Tb); }
+    Fe2<1> T = fe2_mulx<CH>(Ta, Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
     Fe2<1> A = fe2_mulx<CH>(D1, load_fe2_limbs(entry + off_d));
@@ -652,7 +663,10 @@ template <typename SRC> FQ_DEV Proj<1, 1, 1> start_scan(const SRC& src, u32 digi
 }
 // the comb's mixed addition and starting point with every one of the block's entries read (3 coordinates each)
 template <int CH, typename SRC> FQ_DEV R1 add_affine_scan(const R1& q, const SRC& src, u32 idx, u32 neg_mask) {
-    Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
+    Fe2<4> Ta = q.Ta;
+    Fe2<2> Tb = q.Tb;
+    if constexpr (CH == 2) { fe2_here(Ta); fe2_here(Tb); }      // as in add_affine_table: keeps the 90 products single instructions
+    Fe2<1> T = fe2_mulx<CH>(Ta, Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
     Fe2<1> tN = src.coord(idx, 0), tD = src.coord(idx, 1);
