@@ -95,6 +95,11 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
     for k, r in sorted(kernels.items(), key=lambda kv: -kv[1]["share_of_gpu_time_pct"]):
         print("    %-60s %10.1f us x %.2f/step" % (k[:60], r["rocprof_avg_ns"] / 1e3, r["launches_per_step"] or 0))
 if per_workload:
+    try:                                     # a partial re-profile (some workloads only) keeps the other workloads' entries
+        with open(traffic_path) as fh:
+            per_workload = dict(json.load(fh).get("per_workload") or {}, **per_workload)
+    except (OSError, ValueError):
+        pass
     data = {"hbm_bytes_per_launch": per_workload.get("cfg2"), "per_workload": per_workload, "source": "profiles/%s_pmc_<workload>.json" % tag,
             "note": "HBM-side bytes per bench step: sum over the step's kernels of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per step"}
     with open(traffic_path, "w") as fh:
