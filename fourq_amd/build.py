@@ -4,8 +4,15 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
 git-ignored but travels to the GPU box with the tree.
+
+Every compile also asks hipcc for its per-kernel resource report (-Rpass-analysis=kernel-resource-usage); the
+report of the product build is written to fourq_amd/kernel_resources.json and checked against RESOURCE_POLICY below,
+so a compiler or source change that makes a hot kernel spill (or lose its occupancy) fails the build here, on the CPU,
+instead of showing up as a slower -- or, for a kernel with hand-placed waits, wrong -- GPU run.
 """
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -13,10 +20,22 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
+RESOURCES_PATH = os.path.join(HERE, "kernel_resources.json")
 # four translation units: FQ_CHAIN=0 / 1 (kernels.hip.h), and the constant-time-selection builds of both flavours
 SOURCES = ["fourq_amd.hip", "fourq_chain.hip", "fourq_ct_fused.hip", "fourq_ct_chain.hip"]
 HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Rpass-analysis=kernel-resource-usage"]
+
+# (regex on the demangled kernel name, field, predicate, why).  Checked for the product build only (no extra flags).
+RESOURCE_POLICY = [
+    (r"ladder_kernel<\d, 2,", "scratch", lambda v: v == 0,
+     "the two-kernel route's ladders must not spill: they run at 4 waves per SIMD on exactly 128 VGPRs"),
+    (r"ladder_kernel<\d, 2,", "occupancy", lambda v: v >= 4, "the two-kernel route's ladders are sized for 4 waves per SIMD"),
+    (r"ladder_kernel<\d, 1, false", "scratch", lambda v: v == 0, "the fixed-base MUL ladders must not spill"),
+    (r"ladder_kernel<\d, 0,", "scratch", lambda v: v == 0, "the fused variable-base kernels must not spill to memory (AGPR copies are fine)"),
+    (r"prep_kernel<0,", "occupancy", lambda v: v >= 2, "prep_kernel<ENDO> hides its read-backs behind a second wave per SIMD"),
+    (r"comb_kernel<\w+, false>", "scratch", lambda v: v <= 64, "the keygen comb (selection by address) spills 44-64 bytes at its 128-VGPR budget: no more than that"),
+]
 
 
 def _hipcc():
@@ -24,6 +43,48 @@ def _hipcc():
     if not os.path.exists(exe):
         raise RuntimeError("hipcc not found: the FourQ engine needs the ROCm toolchain to build")
     return exe
+
+
+def _demangle(names):
+    filt = shutil.which("c++filt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True, check=True).stdout.splitlines()
+        return [o.replace("fq::(anonymous namespace)::", "").replace("(anonymous namespace)::", "") for o in out]
+    except (OSError, subprocess.CalledProcessError):
+        return list(names)
+
+
+_FIELDS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+           "Occupancy [waves/SIMD]": "occupancy", "VGPRs Spill": "vgpr_spills", "SGPRs Spill": "sgpr_spills", "LDS Size [bytes/block]": "lds"}
+
+
+def parse_resource_remarks(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage output -> {mangled kernel name: {field: int}}."""
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+(Function Name|[A-Za-z ]+(?:\[[^\]]+\])?):\s*(\S+)\s*\[-Rpass-analysis", line)
+        if not m:
+            continue
+        key, val = m.group(1).strip(), m.group(2)
+        if key == "Function Name":
+            cur = kernels.setdefault(val, {})
+        elif cur is not None and key in _FIELDS:
+            try:
+                cur[_FIELDS[key]] = int(val)
+            except ValueError:
+                pass
+    return kernels
+
+
+def check_policy(resources):
+    """Violations of RESOURCE_POLICY in {unit: {demangled kernel: fields}} as a list of strings."""
+    bad = []
+    for unit, kernels in resources.items():
+        for name, f in kernels.items():
+            for pattern, field, ok, why in RESOURCE_POLICY:
+                if re.search(pattern, name) and field in f and not ok(f[field]):
+                    bad.append("%s: %s has %s = %d (%s)" % (unit, name, field, f[field], why))
+    return bad
 
 
 def is_stale():
@@ -36,7 +97,8 @@ def is_stale():
 
 def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
     """Compile the library if it is missing or older than its sources; returns its path.  `out_path` + `extra_flags`
-    build an experiment variant beside the product library (tools/ab_bench.sh compares them on one GPU box)."""
+    build an experiment variant beside the product library (tools/ab_bench.sh compares them on one GPU box); a variant's
+    resource report goes to <out_path>.resources.json and is not policy-checked."""
     if out_path is None and not force and not is_stale():
         return LIB_PATH
     lib_path = out_path or LIB_PATH
@@ -47,18 +109,30 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
         cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(SRC_DIR, src)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        procs.append((src, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
-    for cmd, proc in procs:
+    resources = {}
+    for src, cmd, proc in procs:
         out, _ = proc.communicate()
         if proc.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), "\n".join(l for l in out.splitlines() if "remark:" not in l)))
+        raw = parse_resource_remarks(out)
+        names = list(raw)
+        resources[src] = dict(zip(_demangle(names), (raw[n] for n in names)))
+    bad = check_policy(resources) if out_path is None and not extra_flags else []
+    if bad:
+        raise RuntimeError("kernel resource policy violated (fourq_amd/build.py RESOURCE_POLICY):\n  " + "\n  ".join(bad))
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(link), file=sys.stderr)
     proc = subprocess.run(link, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError("link failed:\n" + proc.stdout + proc.stderr)
+    with open(RESOURCES_PATH if out_path is None else lib_path + ".resources.json", "w") as fh:
+        json.dump(resources, fh, indent=1, sort_keys=True)
+    if out_path is not None:
+        for obj in objs:                                  # a variant's objects have served their purpose
+            os.remove(obj)
     return lib_path
 
 

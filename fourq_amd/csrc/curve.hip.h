@@ -401,6 +401,28 @@ template <typename L, typename P> FQ_DEV void store_r2(P* dst, const R2& t) {
     L::store(dst, t.N); L::store(dst + L::COORD, t.D); L::store(dst + 2 * L::COORD, t.E); L::store(dst + 3 * L::COORD, t.F);
 }
 
+// N and D of +-T for a table entry T: R2neg(T) = (D, N, E, -F) (curve4q.py:193-206).  Both coordinates are read from
+// their own addresses whatever the sign is and exchanged by masked selects -- GFp2.select of fields.py:236-238, one
+// v_bitop3_b32 per limb -- exactly as the reference's selectpt does: the sign of a digit never becomes an address.
+// (FQ_SIGN_BY_ADDRESS=1 restores round 2's address choice for A/B measurements only.)
+#ifndef FQ_SIGN_BY_ADDRESS
+#define FQ_SIGN_BY_ADDRESS 0
+#endif
+template <typename LOAD> FQ_DEV void load_signed_nd(LOAD load, int coord, u32 neg_mask, Fe2<1>& N, Fe2<1>& D) {
+#if FQ_SIGN_BY_ADDRESS
+    const int off_n = neg_mask ? coord : 0, off_d = neg_mask ? 0 : coord;
+    N = load(off_n); D = load(off_d);
+#else
+    const Fe2<1> n = load(0), d = load(coord);
+#if defined(FQ_SIGN_SELECT_XOR)      // A/B only: the xor form, which hipcc turns into three instructions per limb pair
+    N = fe2_select(neg_mask, d, n);
+    D = fe2_select(neg_mask, n, d);
+#else
+    N = fe2_bitselect(neg_mask, d, n);
+    D = fe2_bitselect(neg_mask, n, d);
+#endif
+#endif
+}
 template <int CH, int A, int B> FQ_DEV auto fe2_subx(const Fe2<A>& a, const Fe2<B>& b) {
     if constexpr (CH == 2) return widen<A + B + 1>(fe2_sub_signed(a, b)); else return fe2_sub(a, b);
 }
@@ -409,15 +431,16 @@ template <int CH, int B> FQ_DEV auto fe2_cnegx(const Fe2<B>& x, u32 mask) {
 }
 // Q + (+-T) for a table entry T read coordinate by coordinate from `entry` (HBM scratch or LDS):
 // ADD(Q, selectpt(s, T, R2neg(T))) of curve4q.py:232-233, :440 with R2neg(T) = (D, N, E, -F).  The N/D swap
-// of the negated entry is an address choice, -F is a two-op conditional negation, and each coordinate
-// is loaded just before the product that consumes it, which keeps the live set near 100 VGPRs.
+// of the negated entry is a masked select (load_signed_nd), -F is a two-op conditional negation, and E, F are
+// loaded just before the products that consume them, which keeps the live set near 110 VGPRs.
 template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename L = LimbSlots, typename P> FQ_DEV R1 add_table(const R1& q, const P* entry, u32 neg_mask) {
-    const int off_n = neg_mask ? L::COORD : 0, off_d = neg_mask ? 0 : L::COORD;
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);                          // R1toR3: curve4q.py:119-126
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
-    Fe2<1> A = fe2_mulx<CH>(D1, L::load(entry + off_d));           // ADD_core: curve4q.py:155-171
-    Fe2<1> B = fe2_mulx<CH>(N1, L::load(entry + off_n));
+    Fe2<1> tN, tD;
+    load_signed_nd([&](int off) { return L::load(entry + off); }, L::COORD, neg_mask, tN, tD);
+    Fe2<1> A = fe2_mulx<CH>(D1, tD);                               // ADD_core: curve4q.py:155-171
+    Fe2<1> B = fe2_mulx<CH>(N1, tN);
     Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(L::load(entry + 3 * L::COORD), neg_mask), T);
     Fe2<1> D = fe2_mulx<CH>(L::load(entry + 2 * L::COORD), q.Z);
     Fe2<3> E = fe2_subx<CH>(B, A);
@@ -439,9 +462,8 @@ struct EntryRegs {
 };
 // `ef` (kernels.hip.h: LdsEF / NoEF): where E and F come from -- the entry itself, or the lane's copy of them in LDS
 template <typename L = LimbSlots, typename P, typename EF> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask, u32 digit, const EF& ef) {
-    const int off_n = neg_mask ? L::COORD : 0, off_d = neg_mask ? 0 : L::COORD;
     EntryRegs t;
-    t.N = L::load(entry + off_n); t.D = L::load(entry + off_d);
+    load_signed_nd([&](int off) { return L::load(entry + off); }, L::COORD, neg_mask, t.N, t.D);
     if constexpr (EF::ON) {
         t.E = ef.get(digit, 0); t.F = ef.get(digit, 1);
     } else {
@@ -478,7 +500,6 @@ template <int B> FQ_DEV void fe2_here(Fe2<B>& x) {
     for (int i = 0; i < 5; i++) { FQ_SIGN_UNKNOWN(x.re.l[i]); FQ_SIGN_UNKNOWN(x.im.l[i]); }
 }
 template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_affine_table(const R1& q, const P* entry, u32 neg_mask) {
-    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
     // In the comb's loop Q reaches this addition through a join (the doubling is conditional), and hipcc sign-extends the limbs
     // of Ta and Tb on the far side of it: instruction selection, which works block by block, then sees 64-bit operands and
     // expands each of 90 products into v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3_u32.  Opaque copies keep the limbs 32-bit here.
@@ -488,8 +509,10 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_affine_tab
     Fe2<1> T = fe2_mulx<CH>(Ta, Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
-    Fe2<1> A = fe2_mulx<CH>(D1, load_fe2_limbs(entry + off_d));
-    Fe2<1> B = fe2_mulx<CH>(N1, load_fe2_limbs(entry + off_n));
+    Fe2<1> tN, tD;
+    load_signed_nd([&](int off) { return load_fe2_limbs(entry + off); }, COORD_U32, neg_mask, tN, tD);
+    Fe2<1> A = fe2_mulx<CH>(D1, tD);
+    Fe2<1> B = fe2_mulx<CH>(N1, tN);
     Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(load_fe2_limbs(entry + 2 * COORD_U32), neg_mask), T);
     Fe2<2> D = fe2_dbl(q.Z);
     Fe2<3> E = fe2_subx<CH>(B, A);
@@ -512,8 +535,8 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_affine_tab
 }
 // the comb's starting point: +-A as an R1 point (Z = 1)
 template <typename P> FQ_DEV R1 affine_table_start(const P* entry, u32 neg_mask) {
-    const int off_n = neg_mask ? COORD_U32 : 0, off_d = neg_mask ? 0 : COORD_U32;
-    Fe2<1> N = load_fe2_limbs(entry + off_n), D = load_fe2_limbs(entry + off_d);     // x+y, y-x of +-A
+    Fe2<1> N, D;                                                                     // x+y, y-x of +-A
+    load_signed_nd([&](int off) { return load_fe2_limbs(entry + off); }, COORD_U32, neg_mask, N, D);
     // x = (N - D)/2, y = (N + D)/2: keep the factor 2 projectively: (X, Y, Z) = (N - D, N + D, 2)
     R1 r;
     r.X = fe2_carry(fe2_sub(N, D));
@@ -707,8 +730,8 @@ template <typename SRC> FQ_DEV R1 affine_scan_start(const SRC& src, u32 idx, u32
 
 // R2toR4(selectpt(s, T, nT)): the ladder's starting point (curve4q.py:229, :437)
 template <typename L = LimbSlots, typename P> FQ_DEV Proj<1, 1, 1> start_table(const P* entry, u32 neg_mask) {
-    const int off_n = neg_mask ? L::COORD : 0, off_d = neg_mask ? 0 : L::COORD;
-    Fe2<1> N = L::load(entry + off_n), D = L::load(entry + off_d);
+    Fe2<1> N, D;
+    load_signed_nd([&](int off) { return L::load(entry + off); }, L::COORD, neg_mask, N, D);
     Proj<1, 1, 1> r;
     r.X = fe2_carry(fe2_sub(N, D));
     r.Y = fe2_carry(fe2_add(D, N));

@@ -357,6 +357,19 @@ template <int B> FQ_DEV Fe2<B> fe2_select(u32 mask, const Fe2<B>& x, const Fe2<B
     Fe2<B> r; r.re = fe_select(mask, x.re, y.re); r.im = fe_select(mask, x.im, y.im); return r;
 }
 
+// the same selection as ONE instruction per limb: gfx950's v_bitop3_b32 evaluates any three-input boolean function, here
+// (mask & x) | (~mask & y) (truth table 0xCA).  Written through the builtin because hipcc, given the xor form above for
+// a PAIR of selections (x, y) -> (y, x), shares the x ^ y between them and spends three instructions per limb pair instead of two.
+template <int B> FQ_DEV Fe2<B> fe2_bitselect(u32 mask, const Fe2<B>& x, const Fe2<B>& y) {
+    Fe2<B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        r.re.l[i] = __builtin_amdgcn_bitop3_b32(mask, x.re.l[i], y.re.l[i], 0xCA);
+        r.im.l[i] = __builtin_amdgcn_bitop3_b32(mask, x.im.l[i], y.im.l[i], 0xCA);
+    }
+    return r;
+}
+
 // -x if mask == ~0 else x, branch-free in two cheap ops per limb: bias - x == (bias + 1) + ~x (mod 2^32)
 template <int B> FQ_DEV Fe<B + 1> fe_cneg(const Fe<B>& x, u32 mask) {
     static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");

@@ -322,16 +322,17 @@ template <int ALGO, int SRC, bool DH> constexpr bool signed_ladder() {
 #ifndef FQ_PREBUILT_TOUCH
 #define FQ_PREBUILT_TOUCH 1
 #endif
-// The load lands in its register whenever the memory system answers, and hipcc does not track loads issued from asm: the register
-// must stay reserved until a wait the compiler does track has covered it.  touch_done() after the addition does that: loads return
-// in order, so once the addition's own (younger) loads have been waited for, this one has landed.  `after` is a limb of the sum's X,
-// which depends on all four coordinates of the entry: tying it to the same statement keeps hipcc from moving the release up.
+// The touch is an ordinary load that hipcc sees: it allocates the landing register and places the s_waitcnt that covers it
+// itself (round 2 issued the load from inline asm, where a spill of the untracked register would have corrupted a live limb).
+// touch_done() after the addition is its only consumer; `after` is a limb of the sum's X, which depends on all four coordinates
+// of the entry, so the consumer -- and with it the wait -- cannot move up in front of the addition's own loads, and the
+// scheduling barrier behind the load keeps the load itself at the top of the step.
 template <typename TP> FQ_DEV u32 touch_line(const TP* p) {
-    u32 landing;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(landing) : "v"(p) : "memory");
+    const u32 landing = *reinterpret_cast<const u32*>(p);
+    __builtin_amdgcn_sched_barrier(0);
     return landing;
 }
-FQ_DEV void touch_done(u32 landing, u32& after) { asm volatile("" : "+v"(after) : "v"(landing) : "memory"); }
+FQ_DEV void touch_done(u32 landing, u32& after) { asm volatile("" : "+v"(after) : "v"(landing)); }
 // a ladder on signed limbs (CH == 2) hands its result back with non-negative limbs
 template <int CH> FQ_DEV R1 ladder_result(const R1& Q) {
     if constexpr (CH == 2) {
