@@ -156,15 +156,17 @@ def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
             "per_core": round(per_core / busy, 1)}
 
 
-def c_oracle_gate(workload, data, got_words):
+def c_oracle_gate(workload, data, got_words, world=1):
     """The C restatement (oracle/fourq_oracle.c, OpenMP) over the WHOLE batch of this rank: the parity gate on every
-    output and, for context, its rate on the host cores.  Returns (units per second, threads)."""
+    output and, for context, its rate on the host cores.  Every rank of an N-GPU job runs its own gate at
+    the same time, so each takes its share of the host's cores.  Returns (units per second, threads, expected words)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_c as oc
     from fourq_amd import codec, constants
-    threads = oc.set_num_threads(host_cores())
-    assert threads == host_cores(), "OpenMP did not take the thread count"
+    share = max(1, host_cores() // max(1, world))
+    threads = oc.set_num_threads(share)
+    assert threads == share, "OpenMP did not take the thread count"
     s, k = data["scalars_h"], data["second_h"]
     t0 = time.perf_counter()
     if workload == "cfg2":
@@ -356,7 +358,7 @@ class Bench:
         """Every output of this rank's shard against the C oracle; raises on any difference."""
         import numpy as np
         got = d["out"].cpu().numpy().view(np.uint64)
-        rate, threads, want = c_oracle_gate(workload, d, got)
+        rate, threads, want = c_oracle_gate(workload, d, got, self.world)
         return {"gate": "every output of the shard bit-exact vs oracle/fourq_oracle.c", "ok": True, "units": int(len(got)),
                 "c_oracle_units_per_s": round(rate, 1), "c_oracle_threads": threads}, got, want
 

@@ -32,6 +32,7 @@ PROTOTYPES = {
     "fourq_version": (c_int, []),
     "fourq_strerror": (c_char_p, [c_int]),
     "fourq_last_error": (c_char_p, [c_void_p]),
+    "fourq_device_count": (c_int, [POINTER(c_int)]),
     "fourq_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "fourq_ctx_destroy": (c_int, [c_void_p]),
     "fourq_ctx_set_stream": (c_int, [c_void_p, c_void_p]),

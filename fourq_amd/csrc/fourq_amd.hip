@@ -721,6 +721,19 @@ FQ_API const char* fourq_strerror(int code) {
 }
 FQ_API const char* fourq_last_error(const fourq_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
+FQ_API int fourq_device_count(int* count) {
+    if (!count) return FOURQ_ERR_INVALID;
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return FOURQ_OK; }
+    for (int d = 0; d < n; d++) {                   // devices are numbered as HIP numbers them; a non-gfx950 device ends the usable prefix
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) break;
+        *count = d + 1;
+    }
+    return FOURQ_OK;
+}
+
 FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
     if (!out) return FOURQ_ERR_INVALID;
     *out = nullptr;

@@ -33,6 +33,16 @@ def _host(a, cols, dtype=np.uint64):
     return a
 
 
+def _out(out, n, cols, dtype=np.uint64):
+    """A caller-provided result array (e.g. a row slice of a bigger one, or pinned memory from host_empty) or a fresh one."""
+    shape = (n,) if cols is None else (n, cols)
+    if out is None:
+        return np.empty(shape, dtype=dtype)
+    if out.dtype != dtype or out.shape != shape or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous %s %s array" % (shape, np.dtype(dtype).name))
+    return out
+
+
 class Engine:
     def __init__(self, device=None, stream=None):
         self._lib = _lib.load()
@@ -152,10 +162,7 @@ class Engine:
             raise ValueError("scalars and points differ in length")
         if second_cols is None and b.size != 128:
             raise ValueError("a table is 128 words")
-        if out is None:
-            out = np.empty((len(s), 20), dtype=np.uint64)
-        elif out.dtype != np.uint64 or out.shape != (len(s), 20) or not out.flags.c_contiguous:
-            raise ValueError("out must be a C-contiguous (n, 20) uint64 array")
+        out = _out(out, len(s), 20)
         self._ck(fn(self._ctx, _ptr(s), _ptr(b), _ptr(out), len(s)))
         return out
 
@@ -172,36 +179,35 @@ class Engine:
     def mul_windowed_fixed(self, scalars, table, out=None):
         return self._mul(self._lib.fourq_mul_windowed_fixed_batch, scalars, table, None, out)
 
-    def mul_endo_mixed(self, scalars, points_r1, flags, table):
+    def mul_endo_mixed(self, scalars, points_r1, flags, table, out=None):
         s, p = _host(scalars, 4), _host(points_r1, 20)
         f = _host(flags, None, np.uint8).ravel()
         t = _host(table, None).ravel()
         if not (len(s) == len(p) == len(f)) or t.size != 128:
             raise ValueError("mixed batch: inconsistent shapes")
-        out = np.empty((len(s), 20), dtype=np.uint64)
+        out = _out(out, len(s), 20)
         self._ck(self._lib.fourq_mul_endo_mixed_batch(self._ctx, _ptr(s), _ptr(p), _ptr(f), _ptr(t), _ptr(out), len(s)))
         return out
 
     # ---- Diffie-Hellman ----------------------------------------------------------------------
-    def _dh(self, fn, scalars, points_affine, table):
+    def _dh(self, fn, scalars, points_affine, table, out=None, status=None):
         s, p = _host(scalars, 4), _host(points_affine, 8)
         if len(s) != len(p):
             raise ValueError("scalars and points differ in length")
         t = None if table is None else _host(table, None).ravel()
         if t is not None and t.size != 128:
             raise ValueError("a table is 128 words")
-        out = np.empty((len(s), 8), dtype=np.uint64)
-        status = np.empty(len(s), dtype=np.uint8)
+        out, status = _out(out, len(s), 8), _out(status, len(s), None, np.uint8)
         self._ck(fn(self._ctx, _ptr(s), _ptr(p), _ptr(t), _ptr(out), _ptr(status), len(s)))
         return out, status
 
-    def dh_endo(self, scalars, points_affine, table=None):
-        return self._dh(self._lib.fourq_dh_endo_batch, scalars, points_affine, table)
+    def dh_endo(self, scalars, points_affine, table=None, out=None, status=None):
+        return self._dh(self._lib.fourq_dh_endo_batch, scalars, points_affine, table, out, status)
 
-    def dh_windowed(self, scalars, points_affine, table=None):
-        return self._dh(self._lib.fourq_dh_windowed_batch, scalars, points_affine, table)
+    def dh_windowed(self, scalars, points_affine, table=None, out=None, status=None):
+        return self._dh(self._lib.fourq_dh_windowed_batch, scalars, points_affine, table, out, status)
 
-    def dh_exchange(self, a_scalars, b_scalars, base_affine, table392=None):
+    def dh_exchange(self, a_scalars, b_scalars, base_affine, table392=None, out=None, status=None):
         """One exchange per row: DH_endo(a_i, DH_endo(b_i, base)) (curve4q.py:731), the first half's
         public keys staying on the device (fourq_dh_exchange_batch).
 
@@ -216,8 +222,7 @@ class Engine:
         t = None if table392 is None else _host(table392, None).ravel()
         if t is not None and t.size != 128:
             raise ValueError("a table is 128 words")
-        out = np.empty((len(a), 8), dtype=np.uint64)
-        status = np.empty(len(a), dtype=np.uint8)
+        out, status = _out(out, len(a), 8), _out(status, len(a), None, np.uint8)
         self._ck(self._lib.fourq_dh_exchange_batch(self._ctx, _ptr(a), _ptr(b), _ptr(base), _ptr(t), _ptr(out), _ptr(status), len(a)))
         return out, status
 
@@ -236,14 +241,13 @@ class Engine:
         self._ck(self._lib.fourq_comb_table(self._ctx, _ptr(p), _ptr(out)))
         return out
 
-    def comb_mul(self, scalars, comb):
+    def comb_mul(self, scalars, comb, out=None, status=None):
         """Affine [m_i]B for the comb's base B: ((n, 8) words, status) -- equals R1toAffine(MUL_endo(m_i, B))."""
         s = _host(scalars, 4)
         t = _host(comb, None).ravel()
         if t.size != _lib.COMB_WORDS:
             raise ValueError("a comb table is %d words" % _lib.COMB_WORDS)
-        out = np.empty((len(s), 8), dtype=np.uint64)
-        status = np.empty(len(s), dtype=np.uint8)
+        out, status = _out(out, len(s), 8), _out(status, len(s), None, np.uint8)
         self._ck(self._lib.fourq_comb_mul_batch(self._ctx, _ptr(s), _ptr(t), _ptr(out), _ptr(status), len(s)))
         return out, status
 
@@ -254,22 +258,21 @@ class Engine:
         self._ck(self._lib.fourq_comb_mul_batch_dev(self._ctx, _ptr(scalars), _ptr(t), _ptr(out_affine), _ptr(status), n))
 
     # ---- point compression (32-byte wire format) -------------------------------------------------
-    def encode(self, points_affine):
+    def encode(self, points_affine, out=None):
         """(n, 8) affine words -> (n, 32) uint8 encodings (curve4q.py:41-46)."""
         p = _host(points_affine, 8)
-        out = np.empty((len(p), 32), dtype=np.uint8)
+        out = _out(out, len(p), 32, np.uint8)
         self._ck(self._lib.fourq_encode_batch(self._ctx, _ptr(p), _ptr(out), len(p)))
         return out
 
-    def decode(self, encodings):
+    def decode(self, encodings, out=None, status=None):
         """(n, 32) uint8 -> ((n, 8) affine words, (n,) status) (curve4q.py:49-96; status = _lib.DECODE_*)."""
         b = _host(encodings, 32, np.uint8)
-        out = np.empty((len(b), 8), dtype=np.uint64)
-        status = np.empty(len(b), dtype=np.uint8)
+        out, status = _out(out, len(b), 8), _out(status, len(b), None, np.uint8)
         self._ck(self._lib.fourq_decode_batch(self._ctx, _ptr(b), _ptr(out), _ptr(status), len(b)))
         return out, status
 
-    def dh_bytes(self, scalars, public_keys32, kind="endo", table=None):
+    def dh_bytes(self, scalars, public_keys32, kind="endo", table=None, out=None, status=None):
         """The protocol step of draft-ladd-cfrg-4q section "Diffie-Hellman": decode each 32-byte public key, DH_<kind> with
         the scalar, encode the shared point -- one call, intermediates stay on the GPU (fourq_dh_*_bytes_batch).
         Returns ((n, 32) uint8, status): 0 ok, 1/2 as DH_*, 16 + decode status."""
@@ -279,8 +282,7 @@ class Engine:
         t = None if table is None else _host(table, None).ravel()
         if t is not None and t.size != 128:
             raise ValueError("a table is 128 words")
-        out = np.empty((len(s), 32), dtype=np.uint8)
-        status = np.empty(len(s), dtype=np.uint8)
+        out, status = _out(out, len(s), 32, np.uint8), _out(status, len(s), None, np.uint8)
         fn = self._lib.fourq_dh_endo_bytes_batch if kind == "endo" else self._lib.fourq_dh_windowed_bytes_batch
         self._ck(fn(self._ctx, _ptr(s), _ptr(k), _ptr(t), _ptr(out), _ptr(status), len(s)))
         return out, status

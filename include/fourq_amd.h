@@ -73,6 +73,9 @@ int fourq_version(void);                       /* 10000*major + 100*minor + patc
 const char *fourq_strerror(int code);
 const char *fourq_last_error(const fourq_ctx *ctx);   /* detail of the last FOURQ_ERR_HIP */
 
+/* Number of usable devices (gfx950 only; 0 when there is none -- not an error).  SURVEY.md 8(e): one context per device,
+ * contiguous shards, no exchange step; fourq_amd/multi.py (MultiEngine) is the host-side loop over them. */
+int fourq_device_count(int *count);
 int fourq_ctx_create(int device, fourq_ctx **out);
 int fourq_ctx_destroy(fourq_ctx *ctx);
 /* Use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the

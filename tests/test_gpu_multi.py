@@ -1,0 +1,118 @@
+"""SURVEY.md 8(e) on hardware: the engine's N > 1 paths.
+
+* `MultiEngine` (one context and one host thread per device, contiguous shards, no collective) gives the results of the
+  C oracle / of a single `Engine` for every host-array entry point.  A one-GPU box runs it as two contexts on device 0.
+* `bench.py --gpus 2` in rehearsal mode (both ranks on GPU 0 over gloo) runs the launcher, the per-rank shard, the
+  barrier-bracketed timed region, the whole-shard C-oracle gate on every rank and the gather -- the code the driver's
+  8-GPU run executes with RCCL in place of gloo.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[False, True], ids=["select-by-address", "constant-time"])
+def pair(request):
+    from fourq_amd import Engine, MultiEngine
+    multi, single = MultiEngine([0, 0]), Engine(0)
+    multi.ct_select = single.ct_select = request.param
+    yield multi, single
+    multi.close()
+    single.close()
+
+
+def _inputs(eng, n, seed):
+    from bench import seeded_scalars
+    from fourq_amd import codec, constants
+    g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
+    table = eng.table_endo(g1)
+    s, k = seeded_scalars(seed, n), seeded_scalars(seed + 1, n)
+    return g1, table, s, k
+
+
+def test_device_count_and_shape(pair):
+    from fourq_amd import device_count
+    multi, single = pair
+    assert device_count() >= 1 and len(multi.engines) == 2 and multi.lanes == 2 * single.lanes
+
+
+def test_mul_endo_two_contexts_vs_c_oracle(pair):
+    """2^17 + 1 variable-base elements: both shards take more than one fused generation and differ in size by one."""
+    import oracle_c as oc
+    multi, single = pair
+    n = (1 << 17) + 1
+    g1, table, s, k = _inputs(single, n, 91)
+    pts = multi.mul_endo_fixed(k, table)
+    assert np.array_equal(pts, oc.mul(oc.ENDO, k, None, table))
+    got = multi.mul_endo(s, pts)
+    assert np.array_equal(got, oc.mul(oc.ENDO, s, pts))
+
+
+def test_every_entry_point_matches_the_single_engine(pair):
+    from fourq_amd import codec, constants
+    multi, single = pair
+    n = 4099                                                     # odd: the two shards differ by one row
+    g1, table, s, k = _inputs(single, n, 17)
+    pts = single.mul_endo_fixed(k, table)
+    assert np.array_equal(multi.mul_windowed(s, pts), single.mul_windowed(s, pts))
+    tw = single.table_windowed(g1)
+    assert np.array_equal(multi.mul_windowed_fixed(s, tw), single.mul_windowed_fixed(s, tw))
+    flags = (k[:, 0] & 1).astype(np.uint8)
+    assert np.array_equal(multi.mul_endo_mixed(s, pts, flags, table), single.mul_endo_mixed(s, pts, flags, table))
+    gaff = np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), n, axis=0)
+    gaff[5, 0] ^= 1                                              # one point off the curve: status 1 in the first shard
+    for a, b in zip(multi.dh_endo(k, gaff), single.dh_endo(k, gaff)):
+        assert np.array_equal(a, b)
+    pub, st = single.dh_endo(k, gaff)
+    assert st[5] == 1 and not st[6:].any()
+    for a, b in zip(multi.dh_windowed(s, pub), single.dh_windowed(s, pub)):
+        assert np.array_equal(a, b)
+    for a, b in zip(multi.dh_exchange(s, k, gaff[0]), single.dh_exchange(s, k, gaff[0])):
+        assert np.array_equal(a, b)
+    g392 = single.mul_endo(codec.pack_scalars([392]), g1.reshape(1, 20))[0]
+    comb = single.comb_table(g392)
+    for a, b in zip(multi.comb_mul(k, comb), single.comb_mul(k, comb)):
+        assert np.array_equal(a, b)
+    enc = single.encode(pub[6:])
+    assert np.array_equal(multi.encode(pub[6:]), enc)
+    for a, b in zip(multi.decode(enc), single.decode(enc)):
+        assert np.array_equal(a, b)
+    for a, b in zip(multi.dh_bytes(s[6:], enc), single.dh_bytes(s[6:], enc)):
+        assert np.array_equal(a, b)
+
+
+def test_tiny_and_empty_batches(pair):
+    multi, single = pair
+    g1, table, s, k = _inputs(single, 3, 5)
+    assert np.array_equal(multi.mul_endo_fixed(s[:1], table), single.mul_endo_fixed(s[:1], table))      # one row: second shard empty
+    assert multi.mul_endo_fixed(s[:0], table).shape == (0, 20)
+    pts = single.mul_endo_fixed(k, table)
+    assert np.array_equal(multi.mul_endo(s, pts), single.mul_endo(s, pts))
+    with pytest.raises(ValueError):
+        multi.mul_endo(s, pts[:2])
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2` from a bare shell with FOURQ_BENCH_REHEARSE=1: launcher -> two ranks on GPU 0 over gloo."""
+    env = dict(os.environ, FOURQ_BENCH_REHEARSE="1", FOURQ_BENCH_SETTLE_MS="10")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(var, None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "5", "--warmup", "1",
+                           "--no-cpu-baseline", "--no-configs"], capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and "gloo" in line["config"]["backend"]
+    assert line["parity"]["ok"] is True and line["parity"]["all_ranks_ok"] is True and line["parity"]["units"] == 1 << 16
+    assert line["gather_ms"] > 0 and line["scaling"] == "weak"
+    assert abs(line["value"] - 2 * (1 << 16) / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.01     # whole-job units / max-over-ranks time
+    assert line["parity"]["c_oracle_threads"] >= 1                                                      # each rank took a share of the cores

@@ -121,6 +121,12 @@ def test_no_gpu_means_loud_failure_not_fallback():
         curve4q.MUL_endo(5, (curve4q.Gx, curve4q.Gy))      # shape check precedes any device work (curve4q.py:407)
     with pytest.raises(ValueError):
         curve4q.MUL_endo(1 << 256, G1)
+    # the multi-device front end is as loud: no device, no engine -- and an explicit device list fails on its first context
+    assert fourq_amd.device_count() == 0
+    with pytest.raises(fourq_amd.FourQError, match="no usable gfx950 HIP device"):
+        fourq_amd.MultiEngine()
+    with pytest.raises(fourq_amd.FourQError, match="no usable gfx950 HIP device"):
+        fourq_amd.MultiEngine([0, 0])
 
 
 def test_null_arguments_are_rejected_without_a_device():

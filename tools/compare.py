@@ -115,9 +115,12 @@ def timing_table(n=1 << 16, cpu_ops=20, out=print):
         ]
         out("%-26s %16s %22s %10s" % ("operation", "oracle ms/op (1 core)", "MI355X us/op (batch 2^%d, PCIe incl.)" % (n.bit_length() - 1), "ratio"))
         for name, cpu, gpu in cases:
-            t0 = time.perf_counter()
-            want = [cpu(m, P) for m, P in zip(ms, Ps)]
-            c = (time.perf_counter() - t0) / len(ms)
+            want, per_op = [], []
+            for m, P in zip(ms, Ps):                 # median of the per-operation times: one descheduled call (a fresh
+                t0 = time.perf_counter()             # box still paging its image in) must not decide the row
+                want.append(cpu(m, P))
+                per_op.append(time.perf_counter() - t0)
+            c = sorted(per_op)[len(per_op) // 2]
             gpu()
             t0 = time.perf_counter()
             got = gpu()
