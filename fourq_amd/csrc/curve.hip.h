@@ -550,11 +550,12 @@ template <typename P> FQ_DEV R1 affine_table_start(const P* entry, u32 neg_mask)
 // ---- constant-time selection (FOURQ_CT_SELECT; draft-ladd-cfrg-4q.md:753-758) --------------------------------
 // "Implementations MUST ensure that ... memory addresses accessed do not depend on secret data."  The default ladders
 // above use the digit as an address, exactly as the reference does (curve4q.py:232, :440: T[ind[i]]), and the sign
-// as an address choice.  The sources below read EVERY entry of the table at every step and keep the wanted one with
+// by masked selects (load_signed_nd).  The sources below read EVERY entry of the table at every step and keep the wanted one with
 // masks derived arithmetically from the digit (one v_and_or_b32 per limb and entry); the N/D swap of a negated entry
 // is a masked XOR swap, -F a masked negation.  Same values, hence the same R1 tuples.
-//   ScanMem   the table in LDS (all lanes read the same addresses: broadcasts) or in global memory
-//   ScanRegs  a per-lane table held in registers (fused variable-base kernels: no memory traffic in the ladder)
+//   ScanMem    the table in LDS (all lanes read the same addresses: broadcasts) or in global memory
+//   ScanSplit  a per-lane table: N, D in registers, E, F in the lane's LDS rows (fused variable-base kernels: no global
+//              memory traffic in the ladder)
 FQ_DEV u32 eq_mask(u32 a, u32 b) { return 0u - (u32)(a == b); }
 template <int N> FQ_DEV void masked_or(u32 acc[N], const u32 v[N], u32 m) {
 #pragma unroll
@@ -593,26 +594,6 @@ template <int ENTRIES, typename TP> struct ScanMem {
             masked_or<10>(acc, v1, eq_mask(digit, (u32)k + 1));
             __builtin_amdgcn_sched_barrier(0);
         }
-        return fe2_from_limbs(acc);
-    }
-};
-template <int ENTRIES, int COORDS> struct ScanRegs {
-    u32 w[ENTRIES][COORDS * 10];
-    template <typename L, typename TP> FQ_DEV void load(const TP* tbl) {     // the lane's table, in slot layout L
-#pragma unroll
-        for (int k = 0; k < ENTRIES; k++) {
-#pragma unroll
-            for (int c = 0; c < COORDS; c++) {
-                const Fe2<1> v = L::load(tbl + k * L::ENTRY + c * L::COORD);
-#pragma unroll
-                for (int i = 0; i < 5; i++) { w[k][c * 10 + i] = v.re.l[i]; w[k][c * 10 + 5 + i] = v.im.l[i]; }
-            }
-        }
-    }
-    FQ_DEV Fe2<1> coord(u32 digit, int c) const {
-        u32 acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int k = 0; k < ENTRIES; k++) masked_or<10>(acc, &w[k][c * 10], eq_mask(digit, (u32)k));
         return fe2_from_limbs(acc);
     }
 };

@@ -6,17 +6,18 @@
 // multiplication.  Lanes never communicate; a workgroup is 256 lanes; the grid is sized to the
 // number of resident lanes and strides over the batch.
 //
-//   variable base : the lane builds its own 8-entry R2 table (table_endo / table_windowed) into a 1 856-byte
-//                   slot of HBM scratch (192 bytes per entry), then each ladder step gathers the coordinates
-//                   of the entry its digit selects (wavefront-level gather, one entry per lane) a whole
-//                   doubling ahead of their use.  Large batches build the tables in a kernel of their own into
-//                   packed 128-byte entries (two memory sectors per gather) and ladder at four waves per SIMD.
+//   variable base : the lane builds its own 8-entry R2 table (table_endo / table_windowed): N, D of every entry into
+//                   a 768-byte slot of HBM scratch (96 bytes per entry = two memory sectors), E, F into its rows of
+//                   LDS; each ladder step then gathers the coordinates of the entry its digit selects (wavefront-
+//                   level gather, one entry per lane) a whole doubling ahead of their use.  Large batches build the
+//                   tables in a kernel of their own into packed 128-byte entries and ladder at four waves per SIMD.
 //   fixed base    : the 8-entry table is staged once per workgroup into LDS (padded to dodge bank
 //                   conflicts) and gathered from there.
-//   selection     : the sign of a digit is applied branch-free (address choice for the N/D swap, a two-op
-//                   conditional negation for F); the table index is a per-lane address, as in the reference
-//                   (curve4q.py:232, :440).  With FOURQ_CT_SELECT / fourq_ctx_set_ct_select every step reads the
-//                   whole table instead and selects by masks (fourq_ct_*.hip).
+//   selection     : as the reference's selectpt (curve4q.py:193-206): the sign of a digit is applied by masked selects
+//                   (N/D exchanged by one v_bitop3_b32 per limb, F negated by a two-op conditional negation) and never
+//                   becomes an address; the table index is a per-lane address, as in the reference (curve4q.py:232,
+//                   :440).  With FOURQ_CT_SELECT / fourq_ctx_set_ct_select every step reads the whole table instead
+//                   and selects the entry by masks too (fourq_ct_*.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -325,7 +326,7 @@ struct fourq_ctx {
     size_t split_chunk = 0;        // elements per prep + ladder round (<= lanes_w4)
     bool split_all = false;        // FOURQ_SPLIT_ALL=1: route plain MUL_endo through prep + ladder from split_min on (tests)
     size_t split_endo_min = 0;     // plain MUL_endo batches of at least this many elements take prep + ladder (0: never)
-    u32* scratch = nullptr;        // max(lanes, lanes_w4) x SLOT_U32
+    u32* scratch = nullptr;        // per-lane / per-element table slots: the largest of the three users (fourq_ctx_create)
     u32* table_limbs = nullptr;    // 8 x 48: the staged fixed-base table as working limbs
     u32* table_slots = nullptr;    // the same in the PrebuiltSlots layout
     u64* table_packed = nullptr;   // 128 words
@@ -777,8 +778,10 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
         c->split_chunk = c->lanes_w4;
         if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }
-        size_t slots = c->lanes > c->lanes_w4 ? c->lanes : c->lanes_w4;
-        if (hipMalloc(&c->scratch, slots * SLOT_U32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        size_t scratch_u32 = c->lanes * NDSlots::SLOT;                                   // fused kernels: N, D per resident lane
+        if (c->lanes_w4 * PrebuiltSlots::SLOT > scratch_u32) scratch_u32 = c->lanes_w4 * PrebuiltSlots::SLOT;   // two-kernel route: per element of a round
+        if ((size_t)COMB_POINTS * SLOT_U32 > scratch_u32) scratch_u32 = (size_t)COMB_POINTS * SLOT_U32;         // comb_table_kernel: whole entries
+        if (hipMalloc(&c->scratch, scratch_u32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_slots, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }

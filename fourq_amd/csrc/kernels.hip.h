@@ -7,7 +7,8 @@
 //   fourq_ct_chain.hip  FQ_CHAIN=1  fixed-base (LDS) ladders and comb, the whole table read at every step
 // Measured on MI355X (2^20 elements): chaining each column's carry into the next column's first multiply-add
 // gains 4-10 % for every kernel of the second group and costs the fused kernels 12-15 % when applied wholesale;
-// the fused kernels therefore use it only in their ladders, with preloaded table entries (see below).
+// the fused kernels therefore use it only in their ladders, with preloaded table entries (see "the ladders").
+// Designs that were measured and rejected are kept as patches under tools/experiments/, not as switches in this file.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,29 +21,13 @@
 namespace fq {
 
 constexpr int BLOCK = 256;
-constexpr int SLOT_U32 = LimbSlots::SLOT;   // per-lane scratch: 8 table entries (8 x 48) + P.xyz (30) + Q.xyz (30), 16-byte aligned parts
-constexpr int SLOT_P = LimbSlots::PARK_P, SLOT_Q = LimbSlots::PARK_Q;
+constexpr int SLOT_U32 = LimbSlots::SLOT;   // a whole-entry scratch slot (table_build_kernel, comb_table_kernel): 8 x 48 dwords + two parked points
 // Layout of the slots that prep_kernel fills and ladder_kernel<PREBUILT> gathers from: 2^18 elements in flight make
-// 486 MB of 192-byte entries, past the 256 MiB Infinity Cache, and the DH ladder of BASELINE config 4 then pulls
+// 486 MB of 192-byte entries, past the 256 MiB Infinity Cache, and the DH ladder of BASELINE config 4 then pulled
 // 4 TB/s from HBM; packed 128-byte entries cut that by a third and let a round's tables stay in the cache.
-#ifndef FQ_PREBUILT_PACKED
-#define FQ_PREBUILT_PACKED 1
-#endif
-#if FQ_PREBUILT_PACKED
+// (The fused kernels keep ready-to-use limbs: N, D in compact NDSlots -- 2^16 slots = 50 MB, inside the Infinity Cache --
+// and E, F in LDS, below.)
 typedef PackedSlots PrebuiltSlots;
-#else
-typedef LimbSlots PrebuiltSlots;
-#endif
-// The fused kernels (one wave per SIMD, 2^16 slots = 122 MB: always inside the Infinity Cache) keep ready-to-use limbs
-// unless measurement says otherwise.
-#ifndef FQ_FUSED_PACKED
-#define FQ_FUSED_PACKED 0
-#endif
-#if FQ_FUSED_PACKED
-typedef PackedSlots FusedSlots;
-#else
-typedef LimbSlots FusedSlots;
-#endif
 constexpr int PROJ_PLANES = 8;            // deferred normalisation: the 30 working limbs of (X, Y, Z) in eight uint4 planes
 constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k mod 64 -> eight entries never share a b128 bank group
 
@@ -50,13 +35,7 @@ constexpr int LDS_ENTRY_U32 = 52;      // 48 + 4 pad: entry k starts at bank 52k
 // 2 coordinates x 40 bytes x 256 lanes = exactly the CU's 160 KiB).  A ladder step then gathers only N and D from the lane's
 // HBM slot -- bytes 0..95 of a 192-byte entry: two 64-byte sectors instead of three -- and reads E and F from LDS, with no
 // extra arithmetic.  Layout [entry][coordinate][limb pair][lane] x 8 bytes: a wave's 64 lanes hit 64 distinct bank pairs
-// whatever their digits are.
-#ifndef FQ_FUSED_LDS_EF
-#define FQ_FUSED_LDS_EF 1
-#endif
-#ifndef FQ_CT_LDS_EF            // the constant-time fused kernels too (ScanSplit, curve.hip.h)
-#define FQ_CT_LDS_EF 1
-#endif
+// whatever their digits are.  The constant-time fused kernels use the same layout (ScanSplit, curve.hip.h).
 constexpr int EF_LDS_U32 = 8 * 2 * 5 * 2 * 256;               // dwords: 163 840 bytes
 struct LdsEF {
     static constexpr bool ON = true;
@@ -131,7 +110,7 @@ struct LadderArgs {
     const u32* slot_of;    // PREBUILT, optional (mixed batches): per position, the scratch slot of its table or ~0 = `table`
     const u32* table;      // fixed base: 8 x 48 working limbs (global), staged to LDS
     const u32* table_slots;// the same table in the PrebuiltSlots layout (mixed batches: read through a per-lane pointer)
-    u32* scratch;          // variable base: SLOT_U32 per resident lane (FUSED) or per position of the chunk (PREBUILT)
+    u32* scratch;          // variable base: NDSlots::SLOT dwords per resident lane (FUSED) or PrebuiltSlots::SLOT per position of the chunk (PREBUILT)
     uint4* proj;           // DH, optional: PROJ_PLANES x proj_stride; non-NULL selects the kernels that leave (X, Y, Z)
                            // there for normalize_kernel (always the case on the PREBUILT route)
     u32 proj_stride;       // elements per plane
@@ -242,9 +221,6 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo(const R1& P, u32*
 // their own lines).  build_table_endo above reads back ten times right behind its own stores.  Here every read-back is issued
 // BEFORE the stores of the stretch it belongs to: the base T[0] and the next step's working point ahead of this step's parking /
 // result stores, the base T[m+1] ahead of the store of T[half+m]; step 0 takes P from registers.  Same values, same table.
-#ifndef FQ_PREP_PIPELINED
-#define FQ_PREP_PIPELINED 1
-#endif
 template <typename L = LimbSlots> FQ_DEV void build_table_endo_pipelined(const R1& P, u32* slot) {
     constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
     static_assert(SLOT_Q > SLOT_P && SLOT_Q + 30 <= L::SLOT, "this builder parks two points in the slot");
@@ -283,45 +259,17 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo_pipelined(const R
 }
 
 // ---- the ladders -------------------------------------------------------------------------------
-// The fused MUL_endo kernel runs one wave per SIMD: its ladder uses the chained products only together with
-// register-preloaded table entries (gathers issued a whole doubling ahead); measured 0.416 ms per 2^16 batch
-// against 0.423 plain and 0.463 chained without the preload (hipcc cannot hoist loads across the opaque sums).
-// Which ladders run on signed limbs (fp127.hip.h, "signed flavour"; 5 % fewer instructions per step).  Measured
-// per kernel against the unsigned chained ladder (same-box A/B): the LDS ladders gain 1-5 % and the
-// mixed-batch PREBUILT ladder 2 %; the fused kernels lose 3 %, the split windowed ladder 2 %, the split DH ladder is
-// neutral (with packed entries, round 2: +1 %).  Hence: LDS ladders and the ENDO PREBUILT ladders.
-#ifndef FQ_SIGNED_LADDER
-#define FQ_SIGNED_LADDER 1
-#endif
-#ifndef FQ_SIGNED_DH_PREBUILT          // the split DH ladder too: neutral in round 1, +1 % on cfg4 with packed entries (r02_split_route.txt)
-#define FQ_SIGNED_DH_PREBUILT 1
-#endif
-// Round 1 measured the fused ladders -3 % and the split windowed ladder -2 % on signed limbs; with E, F in LDS, compact N, D slots
-// and packed entries (round 2) the same switch measures +4.4 % on the headline kernel and +2.8 % on MUL_windowed at 2^20
-// (profiles/r02_signed_ladders.txt): every ladder now runs signed.
-#ifndef FQ_SIGNED_FUSED
-#define FQ_SIGNED_FUSED 1
-#endif
-#ifndef FQ_SIGNED_WIN_PREBUILT
-#define FQ_SIGNED_WIN_PREBUILT 1
-#endif
-template <int ALGO, int SRC, bool DH> constexpr bool signed_ladder() {
-    return FQ_SIGNED_LADDER && (SRC == LDS || (SRC == PREBUILT && ALGO == ENDO && (!DH || FQ_SIGNED_DH_PREBUILT)) ||
-                                (SRC == PREBUILT && ALGO == WINDOWED && FQ_SIGNED_WIN_PREBUILT) || (SRC == FUSED && FQ_SIGNED_FUSED));
-}
-#ifndef FQ_FUSED_PRELOAD
-#define FQ_FUSED_PRELOAD 1
-#endif
-#ifndef FQ_FUSED_LADDER_CHAIN
-#define FQ_FUSED_LADDER_CHAIN 1
-#endif
-// FQ_PREBUILT_TOUCH: the two-kernel route's ladder reads a lane's table entry (one 128-byte line of its scratch slot) inside the
+// Every ladder runs the products with chained carries on SIGNED limbs (CH = 2, fp127.hip.h "signed flavour": 5 % fewer
+// instructions per step; per-kernel A/Bs in DESIGN.md section 9 -- round 1 adopted it for the LDS and mixed-batch ladders,
+// round 2's layouts made it pay in the fused and the split ladders too).
+// The fused kernels run one wave per SIMD: their ladder preloads the entry of a step into registers a whole doubling ahead
+// (PRELOAD; measured 0.416 ms per 2^16 batch against 0.423 with plain products and 0.463 chained without the preload: hipcc
+// cannot hoist loads across the opaque partial sums).
+constexpr int LADDER_CH = 2;
+// TOUCH: the two-kernel route's ladder reads a lane's table entry (one 128-byte line of its scratch slot) inside the
 // addition, with no registers to spare for issuing the eight loads a doubling ahead (128-VGPR budget).  A one-dword load of the
 // line at the top of the step, result unused, starts the HBM / Infinity-Cache fetch early: the real loads then hit L2.
 // Same-box A/B (profiles/r02_split_route.txt): cfg5 +2.2 % (two waves per SIMD), cfg4 +0..1 % (four waves hide the latency themselves).
-#ifndef FQ_PREBUILT_TOUCH
-#define FQ_PREBUILT_TOUCH 1
-#endif
 // The touch is an ordinary load that hipcc sees: it allocates the landing register and places the s_waitcnt that covers it
 // itself (round 2 issued the load from inline asm, where a spill of the untracked register would have corrupted a live limb).
 // touch_done() after the addition is its only consumer; `after` is a limb of the sum's X, which depends on all four coordinates
@@ -420,68 +368,6 @@ template <int CH, typename SRC> FQ_DEV R1 ladder_windowed_scan(const WinScalar& 
     return ladder_result<CH>(Q);
 }
 
-// The same table for the fused kernels (one wave per SIMD, up to 512 registers per lane).  gfx950 counts loads and
-// stores in one vmcnt, and once both kinds are in flight a wait for a load is a wait for everything, so a lone wave
-// that reads back what it has just stored sits out a store acknowledgement.  Here every memory operation is issued
-// at a MEMORY POINT, i.e. right after an explicit vmcnt(0) that only meets operations issued at least one formula
-// earlier: results are stored one addition late, operands are requested one addition (or one isogeny) early, and
-// P itself never makes the round trip.  Same DAG, same entries; +1.8 % on the headline kernel.  The extra live
-// registers cost prep_kernel its second wave per SIMD, so prep_kernel keeps the plain version above.
-FQ_DEV void memory_point() {
-    __builtin_amdgcn_sched_barrier(0);
-#ifndef FQ_DIAG_NO_MEMPOINT                    // diagnostic builds of tools/microbench/phases.hip only (results are then wrong)
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0); expcnt and lgkmcnt untouched
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_endo_lone_wave(const R1& P, u32* slot, const EF& ef = EF()) {
-    constexpr int SLOT_P = L::PARK_P, SLOT_Q = L::PARK_Q;
-    static_assert(SLOT_Q > SLOT_P && SLOT_Q + 30 <= L::SLOT, "this builder parks two points in the slot");
-    R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
-    int result_at = 0;
-    Fe2<1> X = P.X, Y = P.Y, Z = P.Z;          // step 0: P; step 1: tau(P), parked by step 0; step 2: phi(P)
-#pragma unroll 1
-    for (int step = 0; step < 3; step++) {
-        memory_point();                        // X, Y, Z (requested during the previous additions) are here
-        store_entry<L>(slot, result_at, result, ef);
-        __builtin_amdgcn_sched_barrier(0);
-        Proj<1, 2, 1> t;
-        if (step == 1) {                       // phi and psi share tau(P), curve4q.py:318-322
-            t.X = X; t.Y = widen<2>(Y); t.Z = Z;
-        } else {
-            t = tau(X, Y, Z);
-            if (step == 0) store_xyz(slot + SLOT_P, t.X, fe2_carry(t.Y), t.Z);
-        }
-        Proj<2, 2, 2> u;
-        if (step == 0) {
-            u = upsilon(t);
-        } else {
-            Proj<1, 1, 1> c = chi(t);
-            u.X = widen<2>(c.X); u.Y = widen<2>(c.Y); u.Z = widen<2>(c.Z);
-        }
-        memory_point();                        // request T[0] one isogeny before the first addition
-        R2 base = load_entry_r2<L>(slot, 0, ef);
-        __builtin_amdgcn_sched_barrier(0);
-        R1 V = tau_dual(u.X, u.Y, u.Z);
-        R3 V3 = r1_to_r3(V);
-        const int half = 1 << step;
-#pragma unroll 1
-        for (int m = 0; m < half; m++) {
-            memory_point();                    // `base` is here; whatever was stored last is acknowledged
-            if (m > 0) store_entry<L>(slot, result_at, result, ef);
-            R2 next = base;
-            if (m + 1 < half) next = load_entry_r2<L>(slot, m + 1, ef);
-            if (m == 0 && step == 0) store_xyz(slot + SLOT_Q, V.X, V.Y, V.Z);
-            if (m == half - 1 && step < 2) load_xyz(slot + (step == 0 ? SLOT_P : SLOT_Q), X, Y, Z);   // for the next step
-            __builtin_amdgcn_sched_barrier(0);
-            result = r1_to_r2(add_core(V3, as_signed(base)));
-            result_at = half + m;
-            base = next;
-        }
-    }
-    store_entry<L>(slot, result_at, result, ef);     // T[7]; the ladder's first gather waits for it
-}
-
 // table_endo for the fused kernels that keep E, F in LDS (LdsEF): the same DAG and the same order as above, but nothing is
 // ever read back from the HBM slot.  The working points and the N, D of the entries that later additions need are parked in
 // the LDS rows of entries that do not exist yet (each entry owns 80 bytes per lane):
@@ -491,23 +377,14 @@ template <typename L = LimbSlots, typename EF = NoEF> FQ_DEV void build_table_en
 //                 that entry's own E, F arrive (an iteration loads its next base BEFORE it stores the previous result)
 // T[0]'s N, D stay in registers.  The HBM slot receives N, D of every entry, write-only; loads and stores share vmcnt on
 // gfx950, so a table phase without loads has nothing to wait for until the ladder's first gather.
-#ifndef FQ_TABLE_LDS_PARK
-#define FQ_TABLE_LDS_PARK 1
-#endif
-// decompose + recode before table_endo in the fused MUL_endo / DH_endo kernels (the digits then live across the table phase)
-#ifndef FQ_RECODE_FIRST
-#define FQ_RECODE_FIRST 0
-#endif
-// FULL: the HBM slot receives whole entries (prep_kernel: another kernel gathers them later), not only N and D.
-template <typename L, typename EF, bool FULL = false> FQ_DEV void build_table_endo_lds(const R1& P, u32* slot, const EF& ef) {
+template <typename L, typename EF> FQ_DEV void build_table_endo_lds(const R1& P, u32* slot, const EF& ef) {
     static_assert(EF::ON, "needs the LDS copy of E and F");
     R2 result = r1_to_r2(P);                   // T[0]; `result` holds the one entry not stored yet
     int result_at = 0;
     const Fe2<1> n0 = result.N, d0 = result.D;
     Fe2<1> X = P.X, Y = P.Y, Z = P.Z;          // step 0: P; step 1: tau(P); step 2: phi(P)
     auto store_result = [&]() {
-        if constexpr (FULL) { store_r2<L>(slot + result_at * L::ENTRY, result); ef.put(result_at, result); }
-        else store_entry<L>(slot, result_at, result, ef);
+        store_entry<L>(slot, result_at, result, ef);
         if (result_at >= 1 && result_at <= 3) ef.park_nd(8 - result_at, result.N, result.D);
     };
 #pragma unroll 1
@@ -547,41 +424,6 @@ template <typename L, typename EF, bool FULL = false> FQ_DEV void build_table_en
     store_result();                            // T[7]
 }
 
-// Experiment (FQ_TABLE_INTERLEAVE=1): the same table as straight-line code with the independent parts side by side --
-// phi(P) beside psi(P) behind the shared tau(P); psi(phi(P)) beside the three additions that do not need it; the last four
-// additions together -- so that a lone wave always has a second dependency chain to issue from.  Same DAG, same entries.
-template <typename L = LimbSlots> FQ_DEV void build_table_endo_interleaved(const R1& P, u32* slot) {
-    const R2 T0 = r1_to_r2(P);
-    store_r2<L>(slot, T0);
-    const Proj<1, 2, 1> t = tau(P.X, P.Y, P.Z);
-    const Proj<2, 2, 2> u = upsilon(t);                                     // phi(P) = tau_dual(upsilon(tau(P)))
-    const Proj<1, 1, 1> c = chi(t);                                         // psi(P) = tau_dual(chi(tau(P)))
-    const R1 Vq = tau_dual(u.X, u.Y, u.Z);
-    const R1 Vr = tau_dual(widen<2>(c.X), widen<2>(c.Y), widen<2>(c.Z));
-    const Proj<1, 2, 1> t2 = tau(Vq.X, Vq.Y, Vq.Z);                          // psi(phi(P)) ...
-    const R3 q3 = r1_to_r3(Vq), r3 = r1_to_r3(Vr);
-    const R2 T1 = r1_to_r2(add_core(q3, as_signed(T0)));                    // ... beside T[1] = Q + T[0]
-    store_r2<L>(slot + 1 * L::ENTRY, T1);
-    const Proj<1, 1, 1> c2 = chi(t2);
-    const R2 T2 = r1_to_r2(add_core(r3, as_signed(T0)));                    //            T[2] = R + T[0]
-    store_r2<L>(slot + 2 * L::ENTRY, T2);
-    const R2 T3 = r1_to_r2(add_core(r3, as_signed(T1)));                    //            T[3] = R + T[1]
-    store_r2<L>(slot + 3 * L::ENTRY, T3);
-    const R1 Vs = tau_dual(widen<2>(c2.X), widen<2>(c2.Y), widen<2>(c2.Z));
-    const R3 s3 = r1_to_r3(Vs);
-    const R2 T4 = r1_to_r2(add_core(s3, as_signed(T0)));                    // T[4 + k] = S + T[k]: four independent additions
-    const R2 T5 = r1_to_r2(add_core(s3, as_signed(T1)));
-    const R2 T6 = r1_to_r2(add_core(s3, as_signed(T2)));
-    const R2 T7 = r1_to_r2(add_core(s3, as_signed(T3)));
-    store_r2<L>(slot + 4 * L::ENTRY, T4);
-    store_r2<L>(slot + 5 * L::ENTRY, T5);
-    store_r2<L>(slot + 6 * L::ENTRY, T6);
-    store_r2<L>(slot + 7 * L::ENTRY, T7);
-}
-#ifndef FQ_TABLE_INTERLEAVE
-#define FQ_TABLE_INTERLEAVE 0
-#endif
-
 FQ_DEV void load_scalar(const u64* p, u64 m[4]) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
@@ -594,17 +436,8 @@ namespace {   // kernels: one private copy per translation unit (their code obje
 // Large variable-base batches, first half: per element, (DH: membership test, cofactor clearing,) table
 // construction into scratch slot `pos`.  Kept apart from the ladder so that the endomorphisms' register
 // appetite (256 VGPRs) does not set the ladder's occupancy.
-// Experiment (FQ_PREP_LDS=1): the table_endo flavour owns the CU's whole LDS (one block per CU, one wave per SIMD) and builds the
-// table the way the fused kernels do (build_table_endo_lds), without read-backs from the slot.  Measured SLOWER than two waves
-// per SIMD that wait on their read-backs: cfg4 -1.2 %, cfg5 -2.5 %, DH_endo at 2^20 -3 % (profiles/r02_split_route.txt) -- the
-// second wave hides more than the waits cost.  Off.
-#ifndef FQ_PREP_LDS
-#define FQ_PREP_LDS 0
-#endif
 template <int ALGO, bool DH>
 __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
-    constexpr bool USE_EF = ALGO == ENDO && FQ_PREP_LDS;
-    __shared__ __attribute__((aligned(16))) u32 lds_mem[USE_EF ? EF_LDS_U32 : 4];
     const u32 pos = blockIdx.x * BLOCK + threadIdx.x;
     if (pos >= (a.n_dev ? *a.n_dev : a.n)) return;
     const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
@@ -617,27 +450,22 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
         P = load_r1(a.points + 20 * (size_t)id);
     }
     u32* slot = a.scratch + (size_t)pos * PrebuiltSlots::SLOT;
-    if constexpr (USE_EF) {
-        LdsEF ef;
-        ef.lane = reinterpret_cast<uint2*>(lds_mem) + threadIdx.x;
-        build_table_endo_lds<PrebuiltSlots, LdsEF, true>(P, slot, ef);
-    } else if (ALGO == ENDO) {
-        if (FQ_PREP_PIPELINED) build_table_endo_pipelined<PrebuiltSlots>(P, slot); else build_table_endo<PrebuiltSlots>(P, slot);
-    } else {
-        build_table_windowed<PrebuiltSlots>(P, slot);
-    }
+    if (ALGO == ENDO) build_table_endo_pipelined<PrebuiltSlots>(P, slot);
+    else build_table_windowed<PrebuiltSlots>(P, slot);
 }
 
 // ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
 // DEFER (DH only): leave (X, Y, Z) in a.proj for normalize_kernel instead of inverting Z here.
-// CT: constant-time table selection (every entry read at every step); FUSED keeps the lane's table in registers,
-// LDS / PREBUILT scan the table where it lies.
+// CT: constant-time table selection (every entry read at every step); FUSED keeps N, D of the lane's table in registers and
+// scans E, F in the lane's LDS rows, LDS scans the shared table where it lies (PREBUILT is not taken in this mode).
 template <int ALGO, int SRC, bool DH, bool DEFER = false, bool CT = false>
 __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
     static_assert(!DEFER || DH, "only DH outputs are normalised");
-    constexpr bool USE_EF = SRC == FUSED && FQ_FUSED_LDS_EF && FQ_FUSED_PRELOAD && (!CT || FQ_CT_LDS_EF);     // LdsEF: the CU's whole LDS for one block
+    static_assert(!(CT && SRC == PREBUILT), "the constant-time mode does not take the two-kernel route");
+    constexpr bool USE_EF = SRC == FUSED;                      // LdsEF: the CU's whole LDS for one block of a fused kernel
     __shared__ __attribute__((aligned(16))) u32 lds_table[SRC == LDS ? 8 * LDS_ENTRY_U32 : (USE_EF ? EF_LDS_U32 : 4)];
     using EF = typename std::conditional<USE_EF, LdsEF, NoEF>::type;
+    using L = typename std::conditional<SRC == PREBUILT, PrebuiltSlots, NDSlots>::type;      // slot layout (unused with SRC == LDS)
     EF ef;
     if constexpr (USE_EF) ef.lane = reinterpret_cast<uint2*>(lds_table) + threadIdx.x;
     if (SRC == LDS) {
@@ -656,12 +484,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
-        using L = typename std::conditional<SRC == PREBUILT, PrebuiltSlots, typename std::conditional<USE_EF, NDSlots, FusedSlots>::type>::type;
-#ifdef FQ_DIAG_SAME_SLOT    // timing diagnostic only (results wrong): every lane of the two-kernel route's ladder reads slot 0, i.e. no table traffic
-        u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : 0) * L::SLOT;
-#else
         u32* slot = SRC == LDS ? nullptr : a.scratch + (size_t)(SRC == FUSED ? lane_slot : pos) * L::SLOT;
-#endif
         const u32* tbl = slot;
         if (SRC == PREBUILT && a.slot_of) {                              // mixed batch: own table or the shared one
             const u32 own = a.slot_of[pos];
@@ -669,8 +492,6 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
         }
 
         uint8_t st = FOURQ_DH_OK;
-        constexpr bool RECODE_FIRST = FQ_RECODE_FIRST && SRC == FUSED && ALGO == ENDO && !CT;
-        EndoDigits e_early = {};
         if (SRC == PREBUILT) {
             if (DH) st = a.status[id];                                  // membership verdict of prep_kernel
         } else {
@@ -682,63 +503,42 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             } else if (SRC == FUSED) {
                 P = load_r1(a.points + 20 * (size_t)id);
             }
-            if constexpr (RECODE_FIRST) {             // integer work on the scalar while the point's HBM load is in flight
-                u64 v[4];
-                decompose(m, v);
-                e_early = recode(v);
-            }
-            if (SRC == FUSED) {
-                if (ALGO == ENDO) {
-                    if constexpr (USE_EF && FQ_TABLE_LDS_PARK) build_table_endo_lds<L>(P, slot, ef);
-                    else if (FQ_TABLE_INTERLEAVE) build_table_endo_interleaved<L>(P, slot);
-                    else build_table_endo_lone_wave<L>(P, slot, ef);
-                } else {
-                    build_table_windowed<L>(P, slot, ef);
-                }
+            if constexpr (SRC == FUSED) {
+                if (ALGO == ENDO) build_table_endo_lds<L>(P, slot, ef); else build_table_windowed<L>(P, slot, ef);
             }
         }
         R1 Q;
+        constexpr int CH = LADDER_CH;
         if (ALGO == ENDO) {
-            EndoDigits e;
-            if constexpr (RECODE_FIRST) {
-                e = e_early;
-            } else {
-                u64 v[4];
-                decompose(m, v);
-                e = recode(v);
-            }
-            constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
-            if constexpr (CT && SRC == FUSED && USE_EF) {
+            u64 v[4];
+            decompose(m, v);
+            const EndoDigits e = recode(v);
+            if constexpr (CT && SRC == FUSED) {
                 ScanSplit<EF> regs;
                 regs.ef = ef;
                 regs.template load<L>(tbl);
                 Q = ladder_endo_scan<CH>(e, regs);
-            } else if constexpr (CT && SRC == FUSED) {
-                ScanRegs<8, 4> regs;
-                regs.template load<L>(tbl);
-                Q = ladder_endo_scan<CH>(e, regs);
             } else if constexpr (CT) {
-                static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
                 Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
-            } else
-            Q = SRC == LDS ? ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32) : ladder_endo<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L, EF, SRC == PREBUILT && FQ_PREBUILT_TOUCH>(e, tbl, L::ENTRY, ef);
+            } else if constexpr (SRC == LDS) {
+                Q = ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32);
+            } else {
+                Q = ladder_endo<CH, SRC == FUSED, L, EF, SRC == PREBUILT>(e, tbl, L::ENTRY, ef);
+            }
         } else {
-            WinScalar w = win_reduce(m);
-            constexpr int CH = ((FQ_CHAIN != 0) || (SRC == FUSED && FQ_FUSED_LADDER_CHAIN)) ? (signed_ladder<ALGO, SRC, DH>() ? 2 : 1) : 0;
-            if constexpr (CT && SRC == FUSED && USE_EF) {
+            const WinScalar w = win_reduce(m);
+            if constexpr (CT && SRC == FUSED) {
                 ScanSplit<EF> regs;
                 regs.ef = ef;
                 regs.template load<L>(tbl);
                 Q = ladder_windowed_scan<CH>(w, regs);
-            } else if constexpr (CT && SRC == FUSED) {
-                ScanRegs<8, 4> regs;
-                regs.template load<L>(tbl);
-                Q = ladder_windowed_scan<CH>(w, regs);
             } else if constexpr (CT) {
-                static_assert(SRC != PREBUILT, "the constant-time mode does not take the two-kernel route");
                 Q = ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
-            } else
-            Q = SRC == LDS ? ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32) : ladder_windowed<CH, SRC == FUSED && FQ_FUSED_PRELOAD, L, EF, SRC == PREBUILT && FQ_PREBUILT_TOUCH>(w, tbl, L::ENTRY, ef);
+            } else if constexpr (SRC == LDS) {
+                Q = ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32);
+            } else {
+                Q = ladder_windowed<CH, SRC == FUSED, L, EF, SRC == PREBUILT>(w, tbl, L::ENTRY, ef);
+            }
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
             if (live) {
@@ -772,7 +572,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 }
 
 // ---- fixed-base comb -------------------------------------------------------------
-constexpr int COMB_POINTS = COMB_POINTS_ALL;                  // 256 (by address) + 80 (constant-time mode)
+constexpr int COMB_POINTS = COMB_POINTS_ALL;                  // 1 024 (by address) + 80 (constant-time mode)
 static_assert(COMB_POINTS == FOURQ_COMB_POINTS, "include/fourq_amd.h and recode.hip.h disagree on the comb's shape");
 constexpr int COMB_ENTRY_U32 = 3 * COORD_U32;                 // (x+y, y-x, 2dxy)
 constexpr int COMB_LDS_U32 = COMB_ENTRY_U32;                  // stride in LDS (pads of 0, 4, 8, 12 dwords measured alike)
@@ -783,7 +583,7 @@ static_assert(COMB_FAST_LDS_BYTES <= 160 * 1024, "the fast comb table must fit t
 #if FQ_CHAIN   // only fourq_chain.hip launches it
 // [m]B, affine, from the comb: 6 doublings + 27 mixed additions per element (constant-time mode: 9 + 49 on the small shape).
 // The block width is the launcher's choice (blockDim.x, a multiple of 64): the table is staged once per block.
-constexpr int COMB_MODE = FQ_SIGNED_LADDER ? 2 : 1;          // the comb's additions run on signed limbs like the LDS ladders
+constexpr int COMB_MODE = LADDER_CH;                          // the comb's additions run on signed limbs like every ladder
 template <bool DEFER, bool CT = false>
 __global__ __launch_bounds__(CT ? BLOCK : COMB_BLOCK_MAX, CT ? 4 : 1) void comb_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n) {
     using S = typename std::conditional<CT, CombScan, CombFast>::type;       // the constant-time mode scans the small sub-table

@@ -38,7 +38,7 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     EndoDigits e = recode(v);
     if (VARIANT == 1) { e.d[0] = e.d[1] = e.d[2] = 0; e.top = 0; }
     uint64_t t3 = stamp();
-    R1 Q = ladder_endo<FQ_SIGNED_FUSED ? 2 : 1, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);
+    R1 Q = ladder_endo<LADDER_CH, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);
     uint64_t t4 = stamp();
     u64 o[20];
     store_r1(o, Q);
