@@ -30,7 +30,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md
-VALU_MAD_PEAK = 1024 * 64 / 4.0 * 2.4e9    # measured: a wave64 v_mad_u64_u32 occupies a SIMD for 4 cycles (profiles/true_rates_r01.txt)
+VALU_MAD_PEAK = 1024 * 64 / 4.0 * 2.4e9    # nominal: a wave64 v_mad_u64_u32 occupies a SIMD for 4 cycles, 1024 SIMDs, 2.4 GHz peak clock
+# What the silicon sustains on a stream of independent v_mad_u64_u32 with every SIMD busy (tools/microbench/true_rates.hip,
+# profiles/true_rates_r01.txt): 1.84 ns per wave64 instruction per SIMD at 8 waves (1.99 at 4) -- the chip does not hold
+# 2.4 GHz under this load.  Fractions against this figure say how far a kernel is from what the multiplier can really deliver.
+VALU_MAD_PEAK_MEASURED = 1024 * 64 / 1.84e-9
 
 # Per workload: algorithmic bytes per unit and algorithmic 32x32->64 multiply-adds per unit (both SURVEY.md 8d: GF(p)
 # mul = 16, GF(p^2) M = 48, S = 32 on the reference's real M/S counts), and the multiply-adds this implementation
@@ -45,7 +49,10 @@ WORKLOADS = {
     "cfg3": dict(batch=1 << 20, steps=60, bytes=32 + 160, alg_mads=91_264, mads=173_600, seed=30002,
                  kernel="ladder_kernel<WINDOWED, LDS>", unit="MUL_windowed(m, G, table)",
                  text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
-    "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, mads=22_500 + 97_600 + 6_800, seed=40002,
+    # cfg4: alg_mads prices BOTH halves at the reference's algorithm (DH_endo with table_endo([392]G): 47 616; DH_endo variable
+    # base: 55 072).  The keygen half actually runs the comb (6 DBL + 27 mixed ADD of 7 M: 6 x 272 + 27 x 336 = 10 704 units
+    # + its share of an inversion ~ 400), so alg_mads_run = 11 104 + 55 072 is the figure comparable with the executed one.
+    "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, alg_mads_run=11_104 + 55_072, mads=22_500 + 97_600 + 6_800, seed=40002,
                  kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
                  unit="exchange = DH_endo(a, DH_endo(b, G)): two DH_core evaluations",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
@@ -55,8 +62,8 @@ WORKLOADS = {
                  kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer",
                  unit="MUL_endo, 50% fixed base / 50% variable base",
                  text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo; "
-                      "the 'persistent kernel + device-side queue' of the config is realised as device-side compaction + ONE "
-                      "pointer-selected ladder launch per round (DESIGN.md section 5: measured faster, results identical)"),
+                      "device-side compaction of the variable-base ids, their tables built by prep_kernel, then ONE pointer-selected "
+                      "ladder launch per round (DESIGN.md section 5)"),
 }
 RANK_SEED_STRIDE = 16        # rank r draws from seed + 16 r (rank 0 = the seeds of SURVEY.md 8d)
 
@@ -219,6 +226,28 @@ def edge_case_check(eng):
     return 3 * len(cases)
 
 
+def valu_roofline(wl, n, kernel_ms):
+    """Multiply-adds per second against the multiplier's ceiling: nominal (4 cycles per wave64 v_mad_u64_u32 at 2.4 GHz) and
+    measured (what a saturating stream of them really sustains on this silicon)."""
+    per_s = n / (kernel_ms * 1e-3)
+    rec = {"bound": "valu-int (v_mad_u64_u32, 4 cycles per wave64 per SIMD)", "peak": round(VALU_MAD_PEAK / 1e12, 3),
+           "peak_measured": round(VALU_MAD_PEAK_MEASURED / 1e12, 3), "unit": "Tmad/s",
+           "algorithmic_mads_per_unit": wl["alg_mads"], "executed_mads_per_unit": wl["mads"],
+           "algorithmic_frac": round(wl["alg_mads"] * per_s / VALU_MAD_PEAK, 4), "executed_frac": round(wl["mads"] * per_s / VALU_MAD_PEAK, 4),
+           "algorithmic_frac_of_measured_peak": round(wl["alg_mads"] * per_s / VALU_MAD_PEAK_MEASURED, 4),
+           "executed_frac_of_measured_peak": round(wl["mads"] * per_s / VALU_MAD_PEAK_MEASURED, 4),
+           "note": "algorithmic = SURVEY.md 8(d) units (GF(p) mul = 16 multiply-adds on 2x64-bit limbs); executed = what the "
+                   "radix-2^26 lazy-limb layout issues (25 per GF(p) mul, no carry chains); peak = nominal 4 cycles per wave64 "
+                   "multiply-add at 2.4 GHz, peak_measured = 1.84 ns per wave64 multiply-add per SIMD sustained with every SIMD busy "
+                   "(profiles/true_rates_r01.txt)"}
+    if "alg_mads_run" in wl:                 # cfg4: the keygen half runs the comb, not the reference's 64-step ladder
+        rec["algorithmic_mads_per_unit_of_the_algorithm_run"] = wl["alg_mads_run"]
+        rec["algorithmic_frac_of_the_algorithm_run"] = round(wl["alg_mads_run"] * per_s / VALU_MAD_PEAK, 4)
+        rec["note"] += "; algorithmic_frac prices both halves of an exchange at the REFERENCE's algorithm (table_endo([392]G) ladder for the " \
+                       "keygen half), ..._of_the_algorithm_run at the comb that is actually executed for it"
+    return rec
+
+
 # ---- one workload on this rank ---------------------------------------------------------------------------------
 class Bench:
     def __init__(self, rank, local_rank, world, rehearse):
@@ -275,6 +304,8 @@ class Bench:
             from fourq_amd import codec
             g392 = eng.mul_endo(codec.pack_scalars([392]), self.g1.reshape(1, 20))[0]      # curve4q.py:758
             comb_h = eng.comb_table(g392)                                     # 1024-point comb of [392]G (draft :725-729)
+            eng.comb_stage(comb_h)                                            # uploaded once; the steps pass None = "the staged table"
+            eng.reserve(n)                                                    # the steps only enqueue (fourq_ctx_reserve)
             mid = torch.empty((n, 8), dtype=torch.int64, device=self.dev)
             out = torch.empty((n, 8), dtype=torch.int64, device=self.dev)
             st1 = torch.empty(n, dtype=torch.uint8, device=self.dev)
@@ -282,7 +313,7 @@ class Bench:
             d["status"] = (st1, st2)
 
             def step():
-                eng.comb_mul_dev(second, comb_h, mid, st1, n)             # == DH_endo(b, G, table_endo([392]G)), affine
+                eng.comb_mul_dev(second, None, mid, st1, n)               # == DH_endo(b, G, table_endo([392]G)), affine
                 eng.dh_endo_dev(scalars, mid, None, out, st2, n)          # DH_endo(a, .)
         else:
             d["table_h"] = self.table_g
@@ -335,22 +366,17 @@ class Bench:
             raise SystemExit("cfg4: unexpected DH failure status")
         total = n * self.world * steps
         ach_gbs = wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = _pmc_traffic(workload, self.eng.build_id)
         rec = {
             "workload": wl["text"], "unit_of_work": wl["unit"], "batch_per_gpu": n, "steps": steps, "warmup": warmup,
             "value": round(total / elapsed, 1), "unit": "scalar-mults/s" if workload != "cfg4" else "exchanges/s",
             "ms_per_step": round(1e3 * elapsed / steps, 4),
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6),
-                         "traffic": None if self.eng.ct_select else _pmc_traffic(workload),     # the PMC passes ran on the default kernels
+                         "traffic": None if self.eng.ct_select else traffic, "traffic_source": traffic_src,     # the PMC passes ran on the default kernels
                          "kernel": wl["kernel"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n,
                          "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
-            "valu_roofline": {
-                "bound": "valu-int (v_mad_u64_u32, 4 cycles per wave64 per SIMD)", "peak": round(VALU_MAD_PEAK / 1e12, 3), "unit": "Tmad/s",
-                "algorithmic_mads_per_unit": wl["alg_mads"], "executed_mads_per_unit": wl["mads"],
-                "algorithmic_frac": round(wl["alg_mads"] * n / (kernel_ms * 1e-3) / VALU_MAD_PEAK, 4),
-                "executed_frac": round(wl["mads"] * n / (kernel_ms * 1e-3) / VALU_MAD_PEAK, 4),
-                "note": "algorithmic = SURVEY.md 8(d) units (GF(p) mul = 16 multiply-adds on 2x64-bit limbs); executed = what the "
-                        "radix-2^26 lazy-limb layout issues (25 per GF(p) mul, no carry chains)"},
+            "valu_roofline": valu_roofline(wl, n, kernel_ms),
         }
         return rec, d
 
@@ -421,24 +447,50 @@ class Bench:
         import numpy as np
         eng = self.eng
         n = len(d["scalars_h"])
-        s_pin = eng.host_array(d["scalars_h"])
-        out_pin = eng.host_empty((n, 20))
+        pins = []
+
+        def pin(a):
+            pins.append(eng.host_array(a))
+            return pins[-1]
+
+        def pin_empty(shape, dtype=np.uint64):
+            pins.append(eng.host_empty(shape, dtype))
+            return pins[-1]
+
         if workload == "cfg2":
-            p_pin = eng.host_array(d["points_h"])
-            call = lambda s, p, o: eng.mul_endo(s, p, out=o)
-            args_pin, args_page = (s_pin, p_pin, out_pin), (d["scalars_h"], d["points_h"], None)
-            bytes_in, bytes_out = 192, 160
+            io, bytes_in, bytes_out = "R1 in / R1 out (the reference's own MUL_* signature)", 192, 160
+            s_pin, p_pin, o_pin = pin(d["scalars_h"]), pin(d["points_h"]), pin_empty((n, 20))
+            calls = {"pinned": lambda: eng.mul_endo(s_pin, p_pin, out=o_pin), "pageable": lambda: eng.mul_endo(d["scalars_h"], d["points_h"])}
+        elif workload == "cfg3":
+            io, bytes_in, bytes_out = "scalar in / R1 out (the reference's own MUL_* signature, table resident)", 32, 160
+            s_pin, o_pin = pin(d["scalars_h"]), pin_empty((n, 20))
+            calls = {"pinned": lambda: eng.mul_windowed_fixed(s_pin, d["table_h"], out=o_pin),
+                     "pageable": lambda: eng.mul_windowed_fixed(d["scalars_h"], d["table_h"])}
+        elif workload == "cfg4":
+            # the host-array exchange call: DH_endo(a, DH_endo(b, G, table_endo([392]G))), public keys never leave the device
+            io, bytes_in, bytes_out = "two scalars in / affine shared point + status out (fourq_dh_exchange_batch)", 64, 65
+            from fourq_amd import codec
+            t392 = eng.table_endo(eng.mul_endo(codec.pack_scalars([392]), self.g1.reshape(1, 20))[0])
+            a_pin, b_pin, o_pin, st_pin = pin(d["scalars_h"]), pin(d["second_h"]), pin_empty((n, 8)), pin_empty((n,), np.uint8)
+
+            def exchange(a, b, o, st):
+                out, status = eng.dh_exchange(a, b, self.g_aff, t392, out=o, status=st)
+                if status.any():
+                    raise SystemExit("cfg4 host-array path: unexpected DH failure status")
+                return out
+            calls = {"pinned": lambda: exchange(a_pin, b_pin, o_pin, st_pin), "pageable": lambda: exchange(d["scalars_h"], d["second_h"], None, None)}
         else:
-            call = lambda s, p, o: eng.mul_windowed_fixed(s, p, out=o)
-            args_pin, args_page = (s_pin, d["table_h"], out_pin), (d["scalars_h"], d["table_h"], None)
-            bytes_in, bytes_out = 32, 160
-        rec = {"io": "R1 in / R1 out: %d B in + %d B out per op (the reference's own MUL_* signature)" % (bytes_in, bytes_out),
-               "batch": n, "reps": reps}
-        for label, args in (("pinned", args_pin), ("pageable", args_page)):
-            call(*args)                                         # sizes the pipeline's buffers
+            io, bytes_in, bytes_out = "scalar + R1 + flag in / R1 out (fourq_mul_endo_mixed_batch)", 193, 160
+            s_pin, p_pin, f_pin, o_pin = pin(d["scalars_h"]), pin(d["points_h"]), pin(d["flags_h"]), pin_empty((n, 20))
+            calls = {"pinned": lambda: eng.mul_endo_mixed(s_pin, p_pin, f_pin, d["table_h"], out=o_pin),
+                     "pageable": lambda: eng.mul_endo_mixed(d["scalars_h"], d["points_h"], d["flags_h"], d["table_h"])}
+        rec = {"io": "%s: %d B in + %d B out per unit" % (io, bytes_in, bytes_out), "batch": n, "reps": reps}
+        for label in ("pinned", "pageable"):
+            call = calls[label]
+            call()                                              # sizes the pipeline's buffers
             t0 = time.perf_counter()
             for _ in range(reps):
-                got = call(*args)
+                got = call()
             dt = (time.perf_counter() - t0) / reps
             if not np.array_equal(got, want_words):
                 raise SystemExit("PARITY FAILURE: host-array path (%s, %s) differs from the C oracle" % (workload, label))
@@ -452,22 +504,49 @@ class Bench:
         rec["note"] = ("value = units / wall-clock of the synchronous host-array call (H2D, kernels, D2H pipelined over chunks of whole "
                        "kernel generations); gbs_* = bytes / summed copy durations (HIP events on the copy streams), i.e. the link rate while a "
                        "copy is running; every output compared with the C oracle")
-        for a in (s_pin, out_pin) + ((p_pin,) if workload == "cfg2" else ()):
+        for a in pins:
             eng.host_free(a)
         return rec
 
+    def ct_select_record(self, workload, n, steps, warmup, want_words, default_ms):
+        """The same workload on a SECOND context with constant-time table selection (fourq_ctx_set_ct_select): every ladder step
+        reads the whole table and keeps the wanted entry by masks.  Outputs must equal the default mode's oracle-checked ones."""
+        import numpy as np
+        import torch
+        from fourq_amd import Engine
+        if getattr(self, "eng_ct", None) is None:
+            self.eng_ct = Engine(self.dev.index, stream=self.stream.cuda_stream)
+            self.eng_ct.ct_select = True
+        default, self.eng = self.eng, self.eng_ct
+        try:
+            rec, d = self.run(workload, n, steps, warmup)
+        finally:
+            self.eng = default
+        ok = want_words is not None and bool(np.array_equal(d["out"].cpu().numpy().view(np.uint64), want_words))
+        if want_words is not None and not ok:
+            raise SystemExit("PARITY FAILURE: constant-time selection mode differs from the C oracle (%s)" % workload)
+        del d
+        torch.cuda.empty_cache()
+        return {"ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit": rec["unit"], "steps": steps, "batch_per_gpu": n,
+                "ratio_vs_default": round(rec["ms_per_step"] / default_ms, 3), "parity_ok": ok if want_words is not None else None}
 
-def _pmc_traffic(workload="cfg2"):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), or None."""
+
+def _pmc_traffic(workload, build_id):
+    """(HBM-side bytes per bench step, where that figure comes from).  The bytes are PMC counter readings of a profile run
+    committed under profiles/ (tools/profile_all.sh), not a property of this run: they are reported only when that profile was
+    taken on the library build that is loaded now, otherwise traffic is None and the source says why."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             data = json.load(fh)
-        if workload == "cfg2":
-            return data.get("hbm_bytes_per_launch")
-        return (data.get("per_workload") or {}).get(workload)
     except (OSError, ValueError):
-        return None
+        return None, {"file": None, "note": "profiles/pmc_traffic.json not found"}
+    src = {"file": "profiles/pmc_traffic.json <- %s" % data.get("source"), "profiled_library_build_id": data.get("library_build_id"),
+           "loaded_library_build_id": build_id, "method": data.get("note")}
+    if not build_id or data.get("library_build_id") != build_id:
+        src["note"] = "the committed PMC profile was taken on another build of the library: no traffic figure is claimed for this one"
+        return None, src
+    return (data.get("per_workload") or {}).get(workload), src
 
 
 # ---- launcher ----------------------------------------------------------------------------------------------------
@@ -502,6 +581,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive host-array measurement")
     ap.add_argument("--no-alongside", action="store_true", help="skip the second operation SURVEY.md 8(d) reports alongside cfg2 / cfg3")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the whole-shard C-oracle gate")
+    ap.add_argument("--no-ct", action="store_true", help="skip the constant-time-selection records (second context, FOURQ_CT_SELECT mode)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -537,8 +617,15 @@ def main():
     if rank == 0 and args.workload in ("cfg2", "cfg3") and not args.no_alongside and not args.no_parity:
         alongside = b.alongside(args.workload, d, steps=100 if args.workload == "cfg2" else 20)
 
+    # constant-time selection mode beside the default, on a second context (one GPU only: the N > 1 runs measure scaling)
+    do_ct = world == 1 and not args.no_ct and not b.eng.ct_select
+    ct = {}
+    if do_ct:
+        ct[args.workload] = b.ct_select_record(args.workload, n, max(5, steps // 5), 2, want, rec["ms_per_step"])
+
     configs = {}
     others = [] if (args.no_configs or args.batch) else [w for w in sorted(WORKLOADS) if w != args.workload]
+    pcie_reps = {"cfg2": 20, "cfg3": 3, "cfg4": 3, "cfg5": 10}
     for w in others:
         r, dw = b.run(w, WORKLOADS[w]["batch"], WORKLOADS[w]["steps"], max(2, args.warmup // 4))
         if args.no_parity:
@@ -547,13 +634,15 @@ def main():
             r["parity"], _, want_w = b.parity_gate(w, dw)
         if world > 1 and w == "cfg4":
             r["gather_ms"] = b.gather_ms(dw["out"], WORKLOADS[w]["batch"])
-        if world == 1 and w == "cfg3" and not args.no_pcie and want_w is not None:
-            r["pcie_inclusive"] = b.pcie_inclusive("cfg3", dw, want_w, reps=3)
+        if world == 1 and not args.no_pcie and want_w is not None:
+            r["pcie_inclusive"] = b.pcie_inclusive(w, dw, want_w, reps=pcie_reps[w])
         if rank == 0 and w == "cfg3" and not args.no_alongside and not args.no_parity:
             r["alongside"] = b.alongside("cfg3", dw, steps=20)
         configs[w] = r
         del dw
         torch.cuda.empty_cache()
+        if do_ct:
+            ct[w] = b.ct_select_record(w, WORKLOADS[w]["batch"], max(5, WORKLOADS[w]["steps"] // 5), 2, want_w, r["ms_per_step"])
 
     if world > 1:                                           # every rank passed its own gate, or the job has already died
         ok = torch.tensor([1.0 if parity["ok"] in (True, None) else 0.0], device="cpu" if rehearse else b.dev)
@@ -566,7 +655,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": rec["workload"], "batch_per_gpu": n, "parallelism": "independent shards x%d, no data-path collective" % world,
                        "clock_settle_ms": b.settle_ms, "table_selection": "constant-time (every entry read, FOURQ_CT_SELECT=1)" if b.eng.ct_select
-                       else "by address, as the reference (default; not constant-time)", "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                       else "as the reference (default): digit = table address (curve4q.py:232, :440), sign = masked select (curve4q.py:193-206); "
+                            "not constant-time in the digit -- see ct_select for the mode that is",
+                       "library": {"version": b.eng.version, "build_id": b.eng.build_id},
+                       "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if world > 1 else None},
             "roofline": rec["roofline"], "valu_roofline": rec["valu_roofline"], "parity": parity,
         }
@@ -579,8 +671,12 @@ def main():
             line["alongside"] = alongside
         if configs:
             line["configs"] = configs
-        if world == 1 and not args.no_pcie and want is not None and args.workload in ("cfg2", "cfg3"):
-            line["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=20 if args.workload == "cfg2" else 3)
+        if world == 1 and not args.no_pcie and want is not None:
+            line["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=pcie_reps[args.workload])
+        if ct:
+            line["ct_select"] = dict(ct, mode="fourq_ctx_set_ct_select(ctx, 1) on a second context: every ladder step reads the whole table and "
+                                              "selects by masks; no address depends on the scalar (DESIGN.md section 10); outputs compared with the "
+                                              "same C-oracle results as the default mode")
         if not args.no_cpu_baseline and got is not None:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             sample = min(n, 1 << 16)
@@ -591,6 +687,8 @@ def main():
                 "sample": "whole batch (%d units) via oracle/fourq_oracle.c (OpenMP), every output compared bit-exact with the GPU's" % n}
             line["cpu_baseline"]["sample"] += "; plus %d edge-case scalar/point pairs (0, 1, 2, N-1, N, N+1, 2N, 2^255, 2^256-1 on +-G), exact" % edge_case_check(b.eng)
         print(json.dumps(line), flush=True)
+    if getattr(b, "eng_ct", None) is not None:
+        b.eng_ct.close()
     b.eng.close()
     if world > 1:
         dist.barrier()

@@ -10,4 +10,4 @@ from ._lib import FourQError  # noqa: F401
 from .engine import Engine, default_engine  # noqa: F401
 from .multi import MultiEngine, device_count  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

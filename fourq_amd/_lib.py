@@ -12,7 +12,7 @@ DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
 DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3
 
 MAX_BATCH = 0xFFFFFF00
-ABI_VERSION = 200                    # fourq_version(): 0.2.0 (round 2: protocol calls, host pipeline, 1 104-point comb table object)
+ABI_VERSION = 300                    # fourq_version(): 0.3.0 (round 3: fourq_device_count, fourq_build_id, fourq_ctx_reserve)
 COMB_POINTS = 1024 + 80              # FOURQ_COMB_POINTS: the fast comb and the one the constant-time mode scans
 COMB_WORDS = COMB_POINTS * 12        # FOURQ_COMB_WORDS
 BYTES_DECODE_BASE = 16
@@ -30,6 +30,7 @@ u8p = POINTER(c_uint8)
 # name -> (restype, argtypes); every symbol include/fourq_amd.h declares
 PROTOTYPES = {
     "fourq_version": (c_int, []),
+    "fourq_build_id": (c_char_p, []),
     "fourq_strerror": (c_char_p, [c_int]),
     "fourq_last_error": (c_char_p, [c_void_p]),
     "fourq_device_count": (c_int, [POINTER(c_int)]),
@@ -40,6 +41,7 @@ PROTOTYPES = {
     "fourq_ctx_set_ct_select": (c_int, [c_void_p, c_int]),
     "fourq_ctx_get_ct_select": (c_int, [c_void_p, POINTER(c_int)]),
     "fourq_ctx_lanes": (c_int, [c_void_p, POINTER(c_size_t)]),
+    "fourq_ctx_reserve": (c_int, [c_void_p, c_size_t]),
     "fourq_host_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "fourq_host_free": (c_int, [c_void_p, c_void_p]),
     "fourq_ctx_host_stats": (c_int, [c_void_p, c_void_p]),
@@ -70,6 +72,7 @@ PROTOTYPES = {
     "fourq_dh_exchange_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_exchange_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_comb_table": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "fourq_comb_stage": (c_int, [c_void_p, c_void_p]),
     "fourq_comb_mul_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_comb_mul_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_encode_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),

@@ -87,6 +87,18 @@ def check_policy(resources):
     return bad
 
 
+def source_id(extra_flags=()):
+    """16 hex digits identifying what a build was made from: the translation units, their headers and the flags.  Compiled into
+    the library (fourq_build_id) so that a profile can say which build it was taken on (bench.py: roofline.traffic_source)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.normpath(os.path.join(SRC_DIR, f)), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -104,9 +116,10 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
     lib_path = out_path or LIB_PATH
     suffix = "" if out_path is None else "." + os.path.splitext(os.path.basename(out_path))[0]
     objs, procs = [], []
+    build_id = ['-DFQ_BUILD_ID="%s"' % source_id(extra_flags)]
     for src in SOURCES:                                   # compile the translation units in parallel (~1 min each)
         obj = os.path.join(SRC_DIR, os.path.splitext(src)[0] + suffix + ".o")
-        cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-c", "-o", obj, os.path.join(SRC_DIR, src)]
+        cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + build_id + ["-c", "-o", obj, os.path.join(SRC_DIR, src)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -455,15 +455,19 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename L = LimbSlots, typename P> 
     r.Tb = H;
     return r;
 }
-// The same addition with the entry's coordinates already in registers (N, D already swapped for a negated
-// entry, F not yet negated): lets a lone wave issue its HBM gathers a whole doubling ahead of their use.
+// The same addition with the entry's coordinates already in registers (as loaded: N, D not yet exchanged and F not yet
+// negated for a negated entry): lets a lone wave issue its HBM gathers a whole doubling ahead of their use.
 struct EntryRegs {
     Fe2<1> N, D, E, F;
 };
 // `ef` (kernels.hip.h: LdsEF / NoEF): where E and F come from -- the entry itself, or the lane's copy of them in LDS
 template <typename L = LimbSlots, typename P, typename EF> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask, u32 digit, const EF& ef) {
     EntryRegs t;
+#if FQ_SIGN_BY_ADDRESS
     load_signed_nd([&](int off) { return L::load(entry + off); }, L::COORD, neg_mask, t.N, t.D);
+#else
+    t.N = L::load(entry); t.D = L::load(entry + L::COORD);          // the sign is applied by add_entry, behind the doubling
+#endif
     if constexpr (EF::ON) {
         t.E = ef.get(digit, 0); t.F = ef.get(digit, 1);
     } else {
@@ -472,11 +476,21 @@ template <typename L = LimbSlots, typename P, typename EF> FQ_DEV EntryRegs load
     return t;
 }
 template <int CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_mask) {
+#if FQ_SIGN_BY_ADDRESS
+    const Fe2<1>& tN = t.N;
+    const Fe2<1>& tD = t.D;
+#else
+    // The masked exchange of N and D must not be scheduled next to the gathers (hipcc does that when it may, and the lone
+    // wave then sits out the gather latency at the top of every step: measured -7 % on the headline kernel).  The mask is
+    // made to depend on the doubled point, so the twenty selects can only issue once the doubling has been computed.
+    asm("" : "+v"(neg_mask) : "v"(q.X.re.l[0]), "v"(q.Y.re.l[0]), "v"(q.Z.re.l[0]));
+    const Fe2<1> tN = fe2_bitselect(neg_mask, t.D, t.N), tD = fe2_bitselect(neg_mask, t.N, t.D);
+#endif
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
-    Fe2<1> A = fe2_mulx<CH>(D1, t.D);
-    Fe2<1> B = fe2_mulx<CH>(N1, t.N);
+    Fe2<1> A = fe2_mulx<CH>(D1, tD);
+    Fe2<1> B = fe2_mulx<CH>(N1, tN);
     Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(t.F, neg_mask), T);
     Fe2<1> D = fe2_mulx<CH>(t.E, q.Z);
     Fe2<3> E = fe2_subx<CH>(B, A);

@@ -179,13 +179,15 @@ __global__ __launch_bounds__(BLOCK) void encode_status_kernel(const u64* affine,
     dst[1] = make_uint4((u32)w[2], (u32)(w[2] >> 32), (u32)w[3], (u32)(w[3] >> 32));
     status[i] = st;
 }
-// one affine point replicated n times (the public base of a batch of exchanges)
-__global__ __launch_bounds__(BLOCK) void broadcast_point_kernel(const u64* point, u64* out, u32 n) {
+// one affine point replicated n times (the public base of a batch of exchanges); the point travels as a kernel argument,
+// so the call neither copies from pageable host memory nor keeps a host buffer alive behind the caller's back
+struct AffineArg { u64 w[FOURQ_AFFINE_WORDS]; };
+__global__ __launch_bounds__(BLOCK) void broadcast_point_kernel(AffineArg point, u64* out, u32 n) {
     u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)i);
 #pragma unroll
-    for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)point[2 * k], (u32)(point[2 * k] >> 32), (u32)point[2 * k + 1], (u32)(point[2 * k + 1] >> 32));
+    for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)point.w[2 * k], (u32)(point.w[2 * k] >> 32), (u32)point.w[2 * k + 1], (u32)(point.w[2 * k + 1] >> 32));
 }
 // status of a two-stage exchange: the first failure of either half (the second half already zeroed its output)
 __global__ __launch_bounds__(BLOCK) void merge_status_kernel(const uint8_t* first, uint8_t* status, u32 n) {
@@ -332,7 +334,6 @@ struct fourq_ctx {
     u64* table_packed = nullptr;   // 128 words
     u32* comb_limbs = nullptr;     // FOURQ_COMB_POINTS x 36 working limbs of the staged comb table
     u64* comb_packed = nullptr;    // FOURQ_COMB_POINTS x 12 words
-    uint64_t base_shadow[FOURQ_AFFINE_WORDS];   // dh_exchange: the base point while its (asynchronous) upload is in flight
     uint64_t table_shadow[FOURQ_TABLE_WORDS];   // host copies of what table_limbs / comb_limbs currently hold
     uint64_t comb_shadow[FOURQ_COMB_WORDS];
     bool table_staged = false, comb_staged = false;
@@ -341,6 +342,7 @@ struct fourq_ctx {
     u32* part_slot = nullptr;      // per element of the round: scratch slot of its table, ~0 = shared table
     u32* part_fix = nullptr;       // constant-time mode: ids of the round's fixed-base elements
     bool ct = false;               // constant-time table selection (FOURQ_CT_SELECT / fourq_ctx_set_ct_select)
+    int mixed_queue = -1;          // mixed batches through the persistent work-queue kernel: 1 always, 0 never, -1 = where it measured faster
     uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
     size_t proj_capacity = 0;
     int norm_k = -1;               // FOURQ_NORM_K: 0 = always invert per element, 2/4/8 = always batch; -1 = by batch size
@@ -432,6 +434,10 @@ template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
     }
     return FOURQ_OK;
 }
+
+// Mixed batches: the persistent work-queue kernel where it measured faster than compaction + prep + pointer-selected ladder
+// (profiles/r03_mixed_queue.txt); FOURQ_MIXED_QUEUE=0|1 forces either.
+bool mixed_queue_default(const fourq_ctx* c) { return true; }
 
 // DH outputs are affine: from two resident generations of lanes upwards each lane meets several elements, and
 // the inversions of K of them are merged into one (normalize_kernel).  Returns K (0: invert per element).
@@ -562,6 +568,9 @@ int grow(fourq_ctx* c, char** buf, size_t* have, size_t want, bool pinned) {
     return FOURQ_OK;
 }
 int ensure_work(fourq_ctx* c, size_t bytes) { return grow(c, &c->work, &c->work_bytes, bytes + bytes / 4, false); }
+// intermediates of the protocol-level calls for n elements (decoded keys / first-half results, their status bytes)
+size_t dh_bytes_work_bytes(size_t n) { return 2 * n * 64 + 2 * align256(n); }
+size_t exchange_work_bytes(size_t n) { return 2 * n * 64 + align256(n); }
 
 using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev, size_t m)>;
 
@@ -708,7 +717,11 @@ extern "C" {
 
 #define FQ_API __attribute__((visibility("default")))
 
-FQ_API int fourq_version(void) { return 200; }    // 0.2.0; fourq_amd/_lib.py checks it at load time
+FQ_API int fourq_version(void) { return 300; }    // 0.3.0; fourq_amd/_lib.py checks it at load time
+#ifndef FQ_BUILD_ID
+#define FQ_BUILD_ID "unknown"
+#endif
+FQ_API const char* fourq_build_id(void) { return FQ_BUILD_ID; }   // fourq_amd/build.py: hash of the sources and flags of this build
 
 FQ_API const char* fourq_strerror(int code) {
     switch (code) {
@@ -775,6 +788,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = getenv("FOURQ_SPLIT_ENDO_MIN")) { long v = atol(env); if (v >= 0) c->split_endo_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
+        if (const char* env = getenv("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
         if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
         c->split_chunk = c->lanes_w4;
         if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }
@@ -785,7 +799,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_slots, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
-        if (hipMalloc(&c->part_counter, 2 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
+        if (hipMalloc(&c->part_counter, 4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }   // n_var, n_fix, queue head
         if (hipMalloc(&c->part_fix, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_list, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_slot, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
@@ -856,6 +870,17 @@ FQ_API int fourq_ctx_sync(fourq_ctx* c) {
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FOURQ_OK;
+}
+// Pre-sizes every buffer a _dev call for up to n elements can need (the deferred-normalisation planes and the intermediates
+// of the protocol-level calls), so that those calls only enqueue: without it the first batch larger than any seen before
+// synchronises the stream and reallocates inside the call (not capturable into a graph).
+FQ_API int fourq_ctx_reserve(fourq_ctx* c, size_t n) {
+    if (!c || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    int rc = ensure_proj(c, n);
+    if (rc) return rc;
+    const size_t a = dh_bytes_work_bytes(n), b = exchange_work_bytes(n);
+    return ensure_work(c, a > b ? a : b);
 }
 FQ_API int fourq_ctx_lanes(const fourq_ctx* c, size_t* lanes) {
     if (!c || !lanes) return FOURQ_ERR_INVALID;
@@ -931,15 +956,29 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     // elements of the round in their natural order: each lane reads its table through a pointer -- its own slot or
     // the shared fixed-base table -- so fixed and variable elements share wavefronts without divergence.
     const size_t per_block = (size_t)BLOCK * PART_PER_LANE;
+    const bool queue = c->mixed_queue >= 0 ? c->mixed_queue != 0 : mixed_queue_default(c);
     for (size_t off = 0; off < n; off += c->split_chunk) {
         const u32 m = (u32)(n - off < c->split_chunk ? n - off : c->split_chunk);
-        HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, 2 * sizeof(u32), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, 4 * sizeof(u32), c->stream));
         hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((m + per_block - 1) / per_block)), dim3(BLOCK), 0, c->stream,
-                           flags + off, m, (u32)off, c->part_list, c->part_slot, c->part_counter, c->ct ? c->part_fix : nullptr);
+                           flags + off, m, (u32)off, c->part_list, c->part_slot, c->part_counter, (c->ct || queue) ? c->part_fix : nullptr);
         HIP_TRY(c, hipGetLastError());
         LadderArgs a = {};
         a.scalars = s; a.points = p; a.out = o; a.n = m;
         a.scratch = c->scratch; a.table = c->table_limbs; a.table_slots = c->table_slots;
+        if (queue) {
+            // BASELINE config 5's mechanism: one persistent kernel, one block per CU, every wave pulling 64-element work items
+            // (variable-base first) from a device-side queue until it is empty (kernels.hip.h, mixed_queue_kernel)
+            const size_t items = ((size_t)m + 63) / 64 + 1, blocks = (items + 3) / 4;
+            const unsigned grid = (unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus);
+            if (c->ct) {
+                HIPRC_TRY(c, ct_launch_mixed_queue(grid, c->stream, a, c->part_list, c->part_fix, c->part_counter, c->part_counter + 2));
+            } else {
+                hipLaunchKernelGGL(mixed_queue_kernel<false>, dim3(grid), dim3(BLOCK), 0, c->stream, a, c->part_list, c->part_fix, c->part_counter, c->part_counter + 2);
+                HIP_TRY(c, hipGetLastError());
+            }
+            continue;
+        }
         if (c->ct) {
             // constant-time selection: which elements are fixed-base is public, the digits are not.  The variable-base
             // ids go through the fused kernel (table in registers), the fixed-base ids through the LDS kernel; both
@@ -997,19 +1036,31 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FOURQ_OK;
 }
+// The staged comb stays on the device between calls.  fourq_comb_stage does the 106 KB compare-and-upload once; batch calls
+// that pass comb == NULL use what is staged and do no host-side work on the table at all (a non-NULL comb is compared with the
+// staged copy on every call, which costs microseconds of host time per call on the key-generation path).
+static int stage_comb(fourq_ctx* c, const uint64_t* comb) {
+    if (c->comb_staged && memcmp(c->comb_shadow, comb, sizeof c->comb_shadow) == 0) return FOURQ_OK;      // as stage_table
+    c->comb_staged = false;
+    memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
+    HIP_TRY(c, hipMemcpyAsync(c->comb_packed, c->comb_shadow, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(comb_unpack_kernel, dim3((COMB_POINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->comb_packed, c->comb_limbs);
+    HIP_TRY(c, hipGetLastError());
+    c->comb_staged = true;
+    return FOURQ_OK;
+}
+FQ_API int fourq_comb_stage(fourq_ctx* c, const uint64_t* comb) {
+    if (!c || !comb) return FOURQ_ERR_INVALID;
+    DeviceGuard g(c->device);
+    return stage_comb(c, comb);
+}
 FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
-    if (!c || !scalars || !comb || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;      // NULL = "the staged table": there must be one
     if (!aligned16(scalars) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    if (!c->comb_staged || memcmp(c->comb_shadow, comb, sizeof c->comb_shadow) != 0) {      // as stage_table
-        c->comb_staged = false;
-        memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
-        HIP_TRY(c, hipMemcpyAsync(c->comb_packed, c->comb_shadow, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(comb_unpack_kernel, dim3((COMB_POINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->comb_packed, c->comb_limbs);
-        HIP_TRY(c, hipGetLastError());
-        c->comb_staged = true;
-    }
+    if (comb) { int rc = stage_comb(c, comb); if (rc) return rc; }
     const int group = normalize_group(c, n);
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
     if (rc) return rc;
@@ -1022,9 +1073,11 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     return FOURQ_OK;
 }
 FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
-    if (!c || !scalars || !comb || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!c || !scalars || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
+    if (comb) { int rc = stage_comb(c, comb); if (rc) return rc; comb = nullptr; }      // compared once, not once per chunk
     PipeArray in[1] = { { (const char*)scalars, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
@@ -1078,7 +1131,7 @@ static int dh_bytes_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const u
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
     const size_t nb = align256(n);
-    int rc = ensure_work(c, 2 * n * 64 + 2 * nb);
+    int rc = ensure_work(c, dh_bytes_work_bytes(n));
     if (rc) return rc;
     uint64_t* pts = (uint64_t*)c->work;                       // decoded public keys
     uint64_t* shared = (uint64_t*)(c->work + n * 64);         // affine shared points
@@ -1123,17 +1176,15 @@ FQ_API int fourq_dh_exchange_batch_dev(fourq_ctx* c, const uint64_t* a, const ui
     if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    const size_t nb = align256(n);
-    int rc = ensure_work(c, 2 * n * 64 + nb + 256);
+    int rc = ensure_work(c, exchange_work_bytes(n));
     if (rc) return rc;
     uint64_t* base = (uint64_t*)c->work;                      // the base point, once per exchange
     uint64_t* mid = (uint64_t*)(c->work + n * 64);            // DH(b_i, base): the public keys
     uint8_t* st_first = (uint8_t*)(c->work + 2 * n * 64);
-    uint64_t* one = (uint64_t*)(st_first + nb);
-    if (base_affine != c->base_shadow) memcpy(c->base_shadow, base_affine, sizeof c->base_shadow);
-    HIP_TRY(c, hipMemcpyAsync(one, c->base_shadow, 64, hipMemcpyHostToDevice, c->stream));
+    AffineArg point;
+    memcpy(point.w, base_affine, sizeof point.w);             // read once, here: the launch carries it
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(broadcast_point_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, one, base, (u32)n);
+    hipLaunchKernelGGL(broadcast_point_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, point, base, (u32)n);
     HIP_TRY(c, hipGetLastError());
     if ((rc = dh_dev(c, ENDO, b, base, table392, mid, st_first, n))) return rc;
     if ((rc = dh_dev(c, ENDO, a, mid, nullptr, out, status, n))) return rc;

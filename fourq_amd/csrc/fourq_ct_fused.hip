@@ -19,4 +19,9 @@ int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const 
     return (int)hipGetLastError();
 }
 
+int ct_launch_mixed_queue(unsigned grid, hipStream_t stream, const LadderArgs& a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head) {
+    hipLaunchKernelGGL(mixed_queue_kernel<true>, dim3(grid), dim3(BLOCK), 0, stream, a, var_list, fix_list, counts, queue_head);
+    return (int)hipGetLastError();
+}
+
 }  // namespace fq

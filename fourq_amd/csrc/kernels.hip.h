@@ -571,6 +571,70 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
     }
 }
 
+// ---- mixed batches: ONE persistent kernel pulling work from a device-side queue (BASELINE config 5) ----------------
+// partition_kernel has compacted the ids of the round's variable-base and fixed-base elements (counts[0], counts[1]).  A work
+// item is 64 elements of one kind; items [0, var_items) are variable-base (fused table_endo + ladder, as ladder_kernel<ENDO,
+// FUSED>), the rest fixed-base (the shared table, gathered through L1 a doubling ahead).  One block per CU owns the CU's LDS
+// (E, F of the lanes' tables) and a scratch slot per lane; each of its four waves loops on its own: take the next item with
+// one atomic, run it, until the queue is empty.  The kind of an item is wave-uniform, so no wave ever diverges, the long
+// items are handed out first, and 65 550 variable-base elements cost one extra item on one SIMD instead of a generation of the
+// whole chip.  CT: constant-time table selection for both kinds (the kind of an element is public, its digits are not).
+// Every wave leaves the loop: the queue head only grows and `total` is fixed before the launch.
+template <bool CT>
+__global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head) {
+    __shared__ __attribute__((aligned(16))) u32 lds_ef[EF_LDS_U32];
+    LdsEF ef;
+    ef.lane = reinterpret_cast<uint2*>(lds_ef) + threadIdx.x;
+    const u32 n_var = counts[0], n_fix = counts[1];
+    const u32 var_items = (n_var + 63) / 64, total = var_items + (n_fix + 63) / 64;
+    u32* slot = a.scratch + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * NDSlots::SLOT;
+    const u32 lane = threadIdx.x & 63;
+    constexpr int CH = LADDER_CH;
+#pragma unroll 1
+    for (;;) {
+        u32 item = 0;
+        if (lane == 0) item = atomicAdd(queue_head, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= total) break;
+        const bool variable = item < var_items;                     // wave-uniform
+        const u32 count = variable ? n_var : n_fix;
+        const u32 pos = (variable ? item : item - var_items) * 64 + lane;
+        const bool live = pos < count;
+        const u32 id = (variable ? var_list : fix_list)[live ? pos : count - 1];   // idle tail lanes redo the last element, store nothing
+        u64 m[4];
+        load_scalar(a.scalars + 4 * (size_t)id, m);
+        R1 Q;
+        if (variable) {
+            const R1 P = load_r1(a.points + 20 * (size_t)id);
+            build_table_endo_lds<NDSlots>(P, slot, ef);
+            u64 v[4];
+            decompose(m, v);
+            const EndoDigits e = recode(v);
+            if constexpr (CT) {
+                ScanSplit<LdsEF> regs;
+                regs.ef = ef;
+                regs.template load<NDSlots>(slot);
+                Q = ladder_endo_scan<CH>(e, regs);
+            } else {
+                Q = ladder_endo<CH, true, NDSlots, LdsEF>(e, (const u32*)slot, NDSlots::ENTRY, ef);
+            }
+        } else {
+            u64 v[4];
+            decompose(m, v);
+            const EndoDigits e = recode(v);
+            if constexpr (CT) Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ a.table, R2_LIMBS });      // wave-uniform addresses
+            else Q = ladder_endo<CH, true, LimbSlots, NoEF>(e, a.table, R2_LIMBS);
+        }
+        if (live) {
+            u64 o[20];
+            store_r1(o, Q);
+            uint4* dst = reinterpret_cast<uint4*>(a.out + 20 * (size_t)id);
+#pragma unroll
+            for (int k = 0; k < 10; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
+        }
+    }
+}
+
 // ---- fixed-base comb -------------------------------------------------------------
 constexpr int COMB_POINTS = COMB_POINTS_ALL;                  // 1 024 (by address) + 80 (constant-time mode)
 static_assert(COMB_POINTS == FOURQ_COMB_POINTS, "include/fourq_amd.h and recode.hip.h disagree on the comb's shape");
@@ -723,6 +787,7 @@ int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, con
 int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
 // constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_mixed_queue(unsigned grid, hipStream_t stream, const LadderArgs& a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head);
 int ct_launch_lds(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);        // defers when a.proj != NULL
 int ct_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n);
 

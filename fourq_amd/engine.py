@@ -133,6 +133,19 @@ class Engine:
         d["gbs_d2h"] = st.d2h_bytes / st.d2h_ms / 1e6 if st.d2h_ms > 0 else None
         return d
 
+    def reserve(self, n):
+        """Size the context's internal buffers for `*_dev` batches of up to n elements (fourq_ctx_reserve): such calls then
+        only enqueue -- no hidden stream synchronisation, capturable into a HIP graph."""
+        self._ck(self._lib.fourq_ctx_reserve(self._ctx, int(n)))
+
+    @property
+    def build_id(self):
+        return self._lib.fourq_build_id().decode()
+
+    @property
+    def version(self):
+        return int(self._lib.fourq_version())
+
     @property
     def lanes(self):
         n = ctypes.c_size_t()
@@ -251,10 +264,21 @@ class Engine:
         self._ck(self._lib.fourq_comb_mul_batch(self._ctx, _ptr(s), _ptr(t), _ptr(out), _ptr(status), len(s)))
         return out, status
 
-    def comb_mul_dev(self, scalars, comb_host, out_affine, status, n):
-        t = _host(comb_host, None).ravel()
+    def comb_stage(self, comb):
+        """Upload a comb table once (fourq_comb_stage); comb_mul_dev(..., comb_host=None, ...) then uses it with no per-call
+        work on the table."""
+        t = _host(comb, None).ravel()
         if t.size != _lib.COMB_WORDS:
             raise ValueError("a comb table is %d words" % _lib.COMB_WORDS)
+        self._ck(self._lib.fourq_comb_stage(self._ctx, _ptr(t)))
+
+    def comb_mul_dev(self, scalars, comb_host, out_affine, status, n):
+        """`comb_host`: the table (compared with the staged copy on every call) or None = the table staged by comb_stage()."""
+        t = None
+        if comb_host is not None:
+            t = _host(comb_host, None).ravel()
+            if t.size != _lib.COMB_WORDS:
+                raise ValueError("a comb table is %d words" % _lib.COMB_WORDS)
         self._ck(self._lib.fourq_comb_mul_batch_dev(self._ctx, _ptr(scalars), _ptr(t), _ptr(out_affine), _ptr(status), n))
 
     # ---- point compression (32-byte wire format) -------------------------------------------------

@@ -70,6 +70,7 @@ typedef struct fourq_ctx fourq_ctx;
 
 /* ---- library / context ---------------------------------------------------------------------- */
 int fourq_version(void);                       /* 10000*major + 100*minor + patch */
+const char *fourq_build_id(void);              /* 16 hex digits: hash of the sources and flags the library was built from */
 const char *fourq_strerror(int code);
 const char *fourq_last_error(const fourq_ctx *ctx);   /* detail of the last FOURQ_ERR_HIP */
 
@@ -83,8 +84,9 @@ int fourq_ctx_destroy(fourq_ctx *ctx);
 int fourq_ctx_set_stream(fourq_ctx *ctx, void *hip_stream);
 int fourq_ctx_sync(fourq_ctx *ctx);
 /* Constant-time table selection (draft-ladd-cfrg-4q.md:753-758: "memory addresses accessed [must] not depend on secret
- * data").  OFF by default: the ladders then use a digit of the scalar as a table address, exactly as the reference
- * does (curve4q.py:232, :440), which is NOT constant-time with respect to the scalar.  ON (this call, or
+ * data").  OFF by default: the ladders then do exactly what the reference does -- a digit of the scalar is a table
+ * address (curve4q.py:232, :440) and the SIGN of the digit is applied by masked selects (curve4q.py:193-206), never by
+ * an address -- which is NOT constant-time with respect to the scalar's digits.  ON (this call, or
  * FOURQ_CT_SELECT=1 in the environment when the context is created): every ladder step reads the whole table and
  * keeps the wanted entry by masks; per-lane tables live in registers; signs are applied arithmetically.  Results are
  * bit-identical in both modes; the price of ON is in DESIGN.md section 10. */
@@ -92,6 +94,12 @@ int fourq_ctx_set_ct_select(fourq_ctx *ctx, int on);
 int fourq_ctx_get_ct_select(const fourq_ctx *ctx, int *on);
 /* Resident lanes the ladder kernels are launched with (scratch is sized for this many). */
 int fourq_ctx_lanes(const fourq_ctx *ctx, size_t *lanes);
+/* Buffer growth.  The context owns the intermediates of the DH and protocol-level calls (deferred-normalisation planes,
+ * decoded keys, first-half results); they grow on demand, and a _dev call whose batch is larger than any seen before
+ * SYNCHRONISES the context's stream and reallocates before it enqueues (such a call cannot be captured into a HIP graph).
+ * fourq_ctx_reserve(ctx, n) sizes them once for batches of up to n elements: afterwards _dev calls of at most n elements
+ * only enqueue.  (The host-pointer calls size their pipeline slots themselves and are synchronous anyway.) */
+int fourq_ctx_reserve(fourq_ctx *ctx, size_t n);
 
 /* Pinned (page-locked) host memory.  The host-pointer batch calls cut their arrays into chunks and overlap the
  * H2D copy, the kernels and the D2H copy of consecutive chunks; arrays that live in pinned memory (from here, from
@@ -198,6 +206,10 @@ int fourq_decode_batch_dev(fourq_ctx *ctx, const uint8_t *in32, uint64_t *out_af
 #define FOURQ_COMB_POINTS 1104
 #define FOURQ_COMB_WORDS (1104 * 12)
 int fourq_comb_table(fourq_ctx *ctx, const uint64_t *p_r1, uint64_t *comb);
+/* The device copy of the comb stays staged between calls.  A batch call with a non-NULL `comb` compares it with the staged
+ * copy (103.5 KiB on the host, per call) and uploads it when it differs; fourq_comb_stage does that once, and batch calls
+ * with comb == NULL then use the staged table without touching it (FOURQ_ERR_INVALID when nothing is staged). */
+int fourq_comb_stage(fourq_ctx *ctx, const uint64_t *comb);
 /* status[i]: FOURQ_DH_OK or FOURQ_DH_NEUTRAL ([m]B is the neutral point); out zeroed in that case */
 int fourq_comb_mul_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *comb, uint64_t *out_affine, uint8_t *status, size_t n);
 int fourq_comb_mul_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *comb, uint64_t *out_affine, uint8_t *status, size_t n);

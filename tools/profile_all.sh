@@ -1,7 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): for every BASELINE workload one bench line, one rocprofv3 kernel trace + stats and
-# three separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ group: the TCC counters do not fit one pass and --pmc must
-# not be combined with other trace domains).
+# three separate PMC passes (FETCH_SIZE / WRITE_SIZE / SQ group: the TCC counters do not fit one pass).  A --pmc pass carries
+# --kernel-trace only (needed for the per-kernel rows); it is never combined with --sys-trace / --runtime-trace or the
+# hip / hsa / memory-copy / scratch-memory / marker domains, which this pool's gpurun refuses (validated on rocprofv3 of ROCm 7.2).
 #   tools/profile_all.sh <tag> [workloads...]      -> gpurun_out/<tag>/<workload>/...
 #   python tools/summarize_profiles.py gpurun_out/<tag> <tag>    (afterwards, anywhere)
 set -o pipefail
