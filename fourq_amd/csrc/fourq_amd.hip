@@ -409,12 +409,13 @@ template <int ALGO, int SRC, bool DH> int launch_ladder(fourq_ctx* c, LadderArgs
     }
     return FOURQ_OK;
 }
-// Which variable-base batches take the two-kernel route (prep_kernel + ladder_kernel<PREBUILT>, 4 waves per SIMD).
-// Measured on MI355X (profiles/r02_split_route.txt): MUL_windowed gains 8 % and DH_* 2-3 % from two resident generations of
-// the fused kernels upwards.  Plain MUL_endo, whose 64-step ladder hardly amortises the second launch, lost 7 % on this route
-// in round 1 (192-byte entries: a round's tables, 486 MB, fell out of the Infinity Cache), gained 1-3 % once the entries were
-// packed, and loses 3-4 % again since the fused kernel keeps E, F in LDS and runs on signed limbs (5.21 ms against 5.43 at
-// 2^20): it stays fused (FOURQ_SPLIT_ENDO_MIN = smallest batch that would take the route, 0 = never).
+// Which variable-base batches take the two-kernel route (prep_kernel + ladder_kernel<PREBUILT>, up to 4 waves per SIMD).
+// Measured on MI355X (profiles/r02_split_route.txt, profiles/r03_cliff.txt): MUL_windowed gains 8 % and DH_* 2-3 % at 2^20, and
+// both 3-6 % from the first element past one resident generation of the fused kernels.  Plain MUL_endo, whose 64-step ladder
+// hardly amortises the second launch, lost 7 % on this route in round 1 (192-byte entries: a round's tables, 486 MB, fell out of
+// the Infinity Cache), gained 1-3 % once the entries were packed, and loses 3-4 % again at 2^20 since the fused kernel keeps E, F
+// in LDS and runs on signed limbs (5.21 ms against 5.43): it stays fused (FOURQ_SPLIT_ENDO_MIN = smallest batch that would take
+// the route, 0 = never).
 bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
     if (c->ct) return false;        // constant-time mode keeps the lane's table in registers: fused kernels only
     if (algo == WINDOWED || dh || c->split_all) return n >= c->split_min;
@@ -436,8 +437,11 @@ template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
 }
 
 // Mixed batches: the persistent work-queue kernel where it measured faster than compaction + prep + pointer-selected ladder
-// (profiles/r03_mixed_queue.txt); FOURQ_MIXED_QUEUE=0|1 forces either.
-bool mixed_queue_default(const fourq_ctx* c) { return true; }
+// (profiles/r03_mixed_queue.txt).  A round that fits one generation of resident lanes is one launch instead of three (2^16
+// elements: 0.39 ms against 0.42, constant-time mode 0.48 against 0.81).  Past that the queue hands a wave a third item as soon
+// as the kinds do not split evenly -- BASELINE config 5's 65 550 variable-base elements of 2^17: 0.88 ms against 0.65 -- where the
+// two-kernel route's ladder still has three free wave slots per SIMD.  FOURQ_MIXED_QUEUE=0|1 forces either.
+bool mixed_queue_default(const fourq_ctx* c, size_t round) { return round <= c->lanes; }
 
 // DH outputs are affine: from two resident generations of lanes upwards each lane meets several elements, and
 // the inversions of K of them are merged into one (normalize_kernel).  Returns K (0: invert per element).
@@ -781,7 +785,9 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = getenv("FOURQ_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) occ = v; }
         c->lanes = (size_t)c->cus * occ * BLOCK;
         c->lanes_w4 = (size_t)c->cus * 4 * BLOCK;
-        c->split_min = 2 * c->lanes;                       // below two full waves of fused work the second launch does not pay
+        // MUL_windowed / DH_* past one fused generation: a second generation of one wave per SIMD costs as much as the first, the
+        // two-kernel route's second wave per SIMD 3-6 % less (profiles/r03_cliff.txt; round 2 switched at two generations)
+        c->split_min = c->lanes + 1;
         if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
         c->split_endo_min = 0;
@@ -956,9 +962,9 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     // elements of the round in their natural order: each lane reads its table through a pointer -- its own slot or
     // the shared fixed-base table -- so fixed and variable elements share wavefronts without divergence.
     const size_t per_block = (size_t)BLOCK * PART_PER_LANE;
-    const bool queue = c->mixed_queue >= 0 ? c->mixed_queue != 0 : mixed_queue_default(c);
     for (size_t off = 0; off < n; off += c->split_chunk) {
         const u32 m = (u32)(n - off < c->split_chunk ? n - off : c->split_chunk);
+        const bool queue = c->mixed_queue >= 0 ? c->mixed_queue != 0 : mixed_queue_default(c, m);
         HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, 4 * sizeof(u32), c->stream));
         hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((m + per_block - 1) / per_block)), dim3(BLOCK), 0, c->stream,
                            flags + off, m, (u32)off, c->part_list, c->part_slot, c->part_counter, (c->ct || queue) ? c->part_fix : nullptr);

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def run_bench(*args):
     env = dict(os.environ)
     env["FOURQ_BENCH_SETTLE_MS"] = "10"
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, env=env, timeout=600)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, env=env, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, "stdout must carry exactly one line: %r" % lines[:3]
@@ -52,9 +52,28 @@ def test_default_line_has_the_contract_keys():
         assert rec["op"].startswith(op) and rec["parity_ok"] is True and rec["ms_per_step"] > 0 and 0 < rec["algorithmic_frac"] < rec["executed_frac"] < 1
     p = line["pcie_inclusive"]
     assert p["value"] < line["value"] and p["gbs_h2d"] > 10 and p["gbs_d2h"] > 10 and p["pageable_caller"]["value"] > 0
+    for name, rec in line["configs"].items():                     # wall-clock first H2D byte to last D2H byte, every config
+        q = rec["pcie_inclusive"]
+        assert 0 < q["value"] < rec["value"] * 1.02 and q["pageable_caller"]["value"] > 0, name
+    # round 3: what the line says about itself
+    assert v["peak_measured"] < v["peak"] and v["executed_frac_of_measured_peak"] > v["executed_frac"]
+    v4 = line["configs"]["cfg4"]["valu_roofline"]
+    assert v4["algorithmic_mads_per_unit_of_the_algorithm_run"] < v4["algorithmic_mads_per_unit"]
+    assert v4["algorithmic_frac_of_the_algorithm_run"] < v4["algorithmic_frac"]
+    lib = line["config"]["library"]
+    assert lib["version"] == 300 and len(lib["build_id"]) == 16
+    src = r["traffic_source"]
+    assert src["loaded_library_build_id"] == lib["build_id"]
+    assert (r["traffic"] is None) == (src.get("profiled_library_build_id") != lib["build_id"])      # a figure only for the build it was measured on
+    assert "masked select" in line["config"]["table_selection"]
+    ct = line["ct_select"]                                         # the constant-time mode, driver-visible: same outputs, its price
+    assert set(ct) == {"cfg2", "cfg3", "cfg4", "cfg5", "mode"}
+    for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+        assert ct[name]["parity_ok"] is True and 0.95 < ct[name]["ratio_vs_default"] < 3.0, name
 
 
 def test_single_workload_line():
-    line = run_bench("--workload", "cfg5", "--steps", "10", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--no-pcie")
+    line = run_bench("--workload", "cfg5", "--steps", "10", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--no-pcie", "--no-ct")
     assert "configs[4]" in line["config"]["workload"] and "configs" not in line and "cpu_baseline" not in line and "alongside" not in line
+    assert "ct_select" not in line and "pcie_inclusive" not in line
     assert line["parity"]["ok"] is True and line["config"]["batch_per_gpu"] == 1 << 17

@@ -110,3 +110,43 @@ def test_comb_keygen_then_dh_in_a_hip_graph(eng):
     assert not wst.any() and not st1.cpu().numpy().any() and np.array_equal(keys.cpu().numpy().view(np.uint64), want_keys)
     want_shared, wst2 = oc.dh(oc.ENDO, a_h, want_keys)
     assert not wst2.any() and not st2.cpu().numpy().any() and np.array_equal(shared.cpu().numpy().view(np.uint64), want_shared)
+
+
+def test_reserved_context_is_capturable_without_a_warm_up_call(monkeypatch):
+    """fourq_ctx_reserve + fourq_comb_stage: a fresh context whose very first DH-sized calls are issued INSIDE a graph capture.
+    FOURQ_NORM_K=2 makes every DH batch take the deferred-normalisation route, whose planes would otherwise be allocated (and
+    the stream synchronised) by the first call that needs them -- which a capture does not allow."""
+    import torch
+    from fourq_amd import Engine, FourQError
+    monkeypatch.setenv("FOURQ_NORM_K", "2")
+    dev = torch.device("cuda", 0)
+    n = 3001
+    b_h, a_h = seeded_scalars(81, n), seeded_scalars(82, n)
+    side = torch.cuda.Stream(device=dev)
+    with Engine(0, stream=side.cuda_stream) as e:
+        b, a = (torch.from_numpy(x.view(np.int64)).to(dev) for x in (b_h, a_h))
+        keys = torch.zeros((n, 8), dtype=torch.int64, device=dev)
+        shared = torch.zeros((n, 8), dtype=torch.int64, device=dev)
+        st1 = torch.empty(n, dtype=torch.uint8, device=dev)
+        st2 = torch.empty(n, dtype=torch.uint8, device=dev)
+        with pytest.raises(FourQError):
+            e.comb_mul_dev(b, None, keys, st1, n)          # nothing staged yet: NULL table is an error, not a crash
+        comb = e.comb_table(codec.pack_point(o.MUL_endo(392, G1)))
+        e.comb_stage(comb)
+        e.reserve(n)
+        e.sync()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            e.comb_mul_dev(b, None, keys, st1, n)          # None = the staged comb: no host-side compare, no upload
+            e.dh_endo_dev(a, keys, None, shared, st2, n)
+            graph.capture_end()
+        graph.replay()
+        torch.cuda.synchronize()
+        gaff = np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0)
+        want_keys, _ = oc.dh(oc.ENDO, b_h, gaff)
+        want_shared, _ = oc.dh(oc.ENDO, a_h, want_keys)
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64), want_keys)
+        assert np.array_equal(shared.cpu().numpy().view(np.uint64), want_shared)
+        assert not st1.cpu().numpy().any() and not st2.cpu().numpy().any()

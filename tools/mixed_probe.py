@@ -8,7 +8,8 @@ stream = torch.cuda.Stream(device=dev); torch.cuda.set_stream(stream)
 eng = Engine(0, stream=stream.cuda_stream)
 g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
 te = eng.table_endo(g1)
-n = 1 << 17
+n = int(os.environ.get('MIXED_N', str(1 << 17)))
+print('n', n, 'queue', os.environ.get('FOURQ_MIXED_QUEUE'), 'ct', os.environ.get('FOURQ_CT_SELECT'))
 s = torch.from_numpy(seeded_scalars(1, n).view(np.int64)).to(dev)
 k = torch.from_numpy(seeded_scalars(2, n).view(np.int64)).to(dev)
 pts = torch.empty((n, 20), dtype=torch.int64, device=dev); eng.mul_endo_fixed_dev(k, te, pts, n)
