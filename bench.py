@@ -541,9 +541,10 @@ def _pmc_traffic(workload, build_id):
             data = json.load(fh)
     except (OSError, ValueError):
         return None, {"file": None, "note": "profiles/pmc_traffic.json not found"}
-    src = {"file": "profiles/pmc_traffic.json <- %s" % data.get("source"), "profiled_library_build_id": data.get("library_build_id"),
+    profiled = (data.get("library_build_ids") or {}).get(workload, data.get("library_build_id"))
+    src = {"file": "profiles/pmc_traffic.json <- %s" % data.get("source"), "profiled_library_build_id": profiled,
            "loaded_library_build_id": build_id, "method": data.get("note")}
-    if not build_id or data.get("library_build_id") != build_id:
+    if not build_id or profiled != build_id:
         src["note"] = "the committed PMC profile was taken on another build of the library: no traffic figure is claimed for this one"
         return None, src
     return (data.get("per_workload") or {}).get(workload), src

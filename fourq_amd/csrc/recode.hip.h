@@ -219,7 +219,9 @@ template <typename S> FQ_DEV CombDigits<S> comb_recode(const u64 m[4]) {
     // register-wide operations per digit instead of a 256-bit shift-and-add (the bit-serial form of the method cost 30
     // instructions per digit, 14 % of the comb kernel's instruction count).  Fixed trip counts: nothing depends on the scalar.
     const plane_t neg = (plane_t)(~sign & mask_d);
-#pragma unroll 1
+    // unrolled in full: with a run-time r the compiler keeps plane[] in scratch memory and indexes it dynamically (44-64 bytes
+    // of scratch per lane in comb_kernel, the one hot kernel that had any)
+#pragma unroll
     for (int r = 1; r < COMB_W; r++) {
         const plane_t low = (plane_t)(c0 & mask_d);
         plane_t T = low;

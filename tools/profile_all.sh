@@ -6,14 +6,14 @@
 #   tools/profile_all.sh <tag> [workloads...]      -> gpurun_out/<tag>/<workload>/...
 #   python tools/summarize_profiles.py gpurun_out/<tag> <tag>    (afterwards, anywhere)
 set -o pipefail
-TAG=${1:-r02}; shift
+TAG=${1:-r03}; shift
 W=${@:-cfg2 cfg3 cfg4 cfg5}
 ROOTDIR=$(pwd)
 export TMPDIR=/tmp
 for w in $W; do
   OUT=$ROOTDIR/gpurun_out/$TAG/$w
   mkdir -p $OUT
-  ARGS="--workload $w --no-configs --no-cpu-baseline --no-pcie --no-alongside"
+  ARGS="--workload $w --no-configs --no-cpu-baseline --no-pcie --no-alongside --no-ct"
   python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
   echo "$w: $(python3 -c "import json;l=json.load(open('$OUT/bench.json'));print(l['value'], l['unit'], l['ms_per_step'], 'ms/step')")"
   cd /tmp

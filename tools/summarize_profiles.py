@@ -34,7 +34,7 @@ def short(name):
 
 
 traffic_path = os.path.join(dst, "pmc_traffic.json")
-per_workload = {}
+per_workload, build_ids = {}, {}
 for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
     w = os.path.basename(wdir)
     # gpurun merges a call's files INTO gpurun_out/: a tag used twice leaves two runs side by side -- take the newest of each kind
@@ -90,6 +90,7 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
     with open(os.path.join(dst, "%s_pmc_%s.json" % (tag, w)), "w") as fh:
         json.dump(out, fh, indent=1)
     per_workload[w] = step_traffic
+    build_ids[w] = ((bench.get("config") or {}).get("library") or {}).get("build_id")
     print("%s: bench %.4f ms/step, rocprof sum %.4f ms/step, traffic %.1f MB/step (algorithmic %.1f MB)" % (
         w, out["bench_ms_per_step"], out["rocprof_ms_per_step"], step_traffic / 1e6, out["algorithmic_bytes_per_step"] / 1e6))
     for k, r in sorted(kernels.items(), key=lambda kv: -kv[1]["share_of_gpu_time_pct"]):
@@ -97,10 +98,13 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
 if per_workload:
     try:                                     # a partial re-profile (some workloads only) keeps the other workloads' entries
         with open(traffic_path) as fh:
-            per_workload = dict(json.load(fh).get("per_workload") or {}, **per_workload)
+            old = json.load(fh)
+        per_workload = dict(old.get("per_workload") or {}, **per_workload)
+        build_ids = dict(old.get("library_build_ids") or {}, **build_ids)
     except (OSError, ValueError):
         pass
     data = {"hbm_bytes_per_launch": per_workload.get("cfg2"), "per_workload": per_workload, "source": "profiles/%s_pmc_<workload>.json" % tag,
+            "library_build_ids": build_ids, "library_build_id": build_ids.get("cfg2"),
             "note": "HBM-side bytes per bench step: sum over the step's kernels of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per step"}
     with open(traffic_path, "w") as fh:
         json.dump(data, fh, indent=1)
