@@ -337,6 +337,7 @@ struct fourq_ctx {
     uint64_t table_shadow[FOURQ_TABLE_WORDS];   // host copies of what table_limbs / comb_limbs currently hold
     uint64_t comb_shadow[FOURQ_COMB_WORDS];
     bool table_staged = false, comb_staged = false;
+    hipEvent_t shadow_read = nullptr;   // recorded behind every upload from a shadow: a shadow is rewritten only after its last upload has read it
     u32* part_counter = nullptr;   // mixed batches: number of variable-base elements of the current round (device side)
     u32* part_list = nullptr;      // their ids, split_chunk entries
     u32* part_slot = nullptr;      // per element of the round: scratch slot of its table, ~0 = shared table
@@ -461,11 +462,20 @@ int ensure_proj(fourq_ctx* c, size_t n) {
 
 // The working-limb copy of the caller's fixed-base table stays staged between calls: a call with the same 1 KiB
 // (compared on the host) skips the copy and the unpack launch.
+// The uploads read the context's shadow copies asynchronously.  HIP stages a copy from pageable memory before hipMemcpyAsync
+// returns, but the API does not promise it: the event makes "the previous upload has read its shadow" explicit before a shadow
+// is overwritten (only when the caller's table changes, i.e. never in a steady-state or captured sequence).
+int shadow_free(fourq_ctx* c) {
+    HIP_TRY(c, hipEventSynchronize(c->shadow_read));
+    return FOURQ_OK;
+}
 int stage_table(fourq_ctx* c, const uint64_t* table_host) {
     if (c->table_staged && memcmp(c->table_shadow, table_host, sizeof c->table_shadow) == 0) return FOURQ_OK;
     c->table_staged = false;
+    if (int rc = shadow_free(c)) return rc;
     memcpy(c->table_shadow, table_host, sizeof c->table_shadow);
     HIP_TRY(c, hipMemcpyAsync(c->table_packed, c->table_shadow, FOURQ_TABLE_WORDS * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->shadow_read, c->stream));
     hipLaunchKernelGGL(table_unpack_kernel, dim3(1), dim3(64), 0, c->stream, c->table_packed, c->table_limbs, c->table_slots);
     HIP_TRY(c, hipGetLastError());
     c->table_staged = true;
@@ -777,6 +787,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
                 hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess) rc = FOURQ_ERR_HIP;
         }
         if (rc) break;
+        if (hipEventCreateWithFlags(&c->shadow_read, hipEventDisableTiming) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
         if (chain_setup_device() != 0) { rc = FOURQ_ERR_HIP; break; }
         // resident blocks per CU of the fused variable-base kernels (they own the per-lane scratch slots)
         int occ = 8, o = 0;
@@ -836,6 +847,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->work) (void)hipFree(c->work);
     if (c->pipe_dev) (void)hipFree(c->pipe_dev);
     if (c->pipe_pin) (void)hipHostFree(c->pipe_pin);
+    if (c->shadow_read) (void)hipEventDestroy(c->shadow_read);
     for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
     for (int i = 0; i < PIPE_SLOTS; i++) {
         if (c->in_done[i]) (void)hipEventDestroy(c->in_done[i]);
@@ -1048,8 +1060,10 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
 static int stage_comb(fourq_ctx* c, const uint64_t* comb) {
     if (c->comb_staged && memcmp(c->comb_shadow, comb, sizeof c->comb_shadow) == 0) return FOURQ_OK;      // as stage_table
     c->comb_staged = false;
+    if (int rc = shadow_free(c)) return rc;
     memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
     HIP_TRY(c, hipMemcpyAsync(c->comb_packed, c->comb_shadow, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->shadow_read, c->stream));
     hipLaunchKernelGGL(comb_unpack_kernel, dim3((COMB_POINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->comb_packed, c->comb_limbs);
     HIP_TRY(c, hipGetLastError());
     c->comb_staged = true;
