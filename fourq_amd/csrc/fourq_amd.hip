@@ -812,11 +812,13 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         size_t scratch_u32 = c->lanes * NDSlots::SLOT;                                   // fused kernels: N, D per resident lane
         if (c->lanes_w4 * PrebuiltSlots::SLOT > scratch_u32) scratch_u32 = c->lanes_w4 * PrebuiltSlots::SLOT;   // two-kernel route: per element of a round
         if ((size_t)COMB_POINTS * SLOT_U32 > scratch_u32) scratch_u32 = (size_t)COMB_POINTS * SLOT_U32;         // comb_table_kernel: whole entries
+        const size_t ct_tail_u32 = c->lanes * NDSlots::SLOT + (c->lanes / 8) * LimbSlots::SLOT;                 // constant-time mixed rounds: fused slots + the overflow ids' whole entries
+        if (ct_tail_u32 > scratch_u32) scratch_u32 = ct_tail_u32;
         if (hipMalloc(&c->scratch, scratch_u32 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_limbs, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_slots, 8 * R2_LIMBS * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->table_packed, FOURQ_TABLE_WORDS * 8) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
-        if (hipMalloc(&c->part_counter, 4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }   // n_var, n_fix, queue head
+        if (hipMalloc(&c->part_counter, 8 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }   // n_var, n_fix, queue head, -, fused, overflow
         if (hipMalloc(&c->part_fix, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_list, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
         if (hipMalloc(&c->part_slot, c->lanes_w4 * sizeof(u32)) != hipSuccess) { rc = FOURQ_ERR_NOMEM; break; }
@@ -977,7 +979,7 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     for (size_t off = 0; off < n; off += c->split_chunk) {
         const u32 m = (u32)(n - off < c->split_chunk ? n - off : c->split_chunk);
         const bool queue = c->mixed_queue >= 0 ? c->mixed_queue != 0 : mixed_queue_default(c, m);
-        HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, 4 * sizeof(u32), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->part_counter, 0, 8 * sizeof(u32), c->stream));
         hipLaunchKernelGGL(partition_kernel, dim3((unsigned)((m + per_block - 1) / per_block)), dim3(BLOCK), 0, c->stream,
                            flags + off, m, (u32)off, c->part_list, c->part_slot, c->part_counter, (c->ct || queue) ? c->part_fix : nullptr);
         HIP_TRY(c, hipGetLastError());
@@ -1001,11 +1003,18 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
             // constant-time selection: which elements are fixed-base is public, the digits are not.  The variable-base
             // ids go through the fused kernel (table in registers), the fixed-base ids through the LDS kernel; both
             // read their element counts on the device.
-            LadderArgs av = a, af = a;
-            av.index = c->part_list; av.n_dev = c->part_counter;
-            af.index = c->part_fix; af.n_dev = c->part_counter + 1;
+            // A remainder of at most lanes / 8 ids past whole generations of the fused kernel is cut off on the device and
+            // runs with the fixed-base elements (kernels.hip.h, mixed_ct_tail_kernel): config 5's 65 550 variable-base ids
+            // are one fused generation + 14 riders, not two generations.
+            const u32 limit = (u32)(c->lanes / 8);
+            u32* over_scratch = c->scratch + c->lanes * NDSlots::SLOT;           // behind the fused kernels' per-lane slots
+            HIPRC_TRY(c, ct_launch_split_counts(c->stream, c->part_counter, (u32)c->lanes, limit));
+            LadderArgs av = a;
+            av.index = c->part_list; av.n_dev = c->part_counter + 4;
             if ((rc = launch_ladder<ENDO, FUSED, false>(c, av))) return rc;
-            if ((rc = launch_ladder<ENDO, LDS, false>(c, af))) return rc;
+            const size_t tail_blocks = ((size_t)m + BLOCK - 1) / BLOCK, tail_max = c->lanes_w4 / BLOCK;
+            HIPRC_TRY(c, ct_launch_mixed_tail((limit + BLOCK - 1) / BLOCK, (unsigned)(tail_blocks < tail_max ? tail_blocks : tail_max), c->stream, a,
+                                              c->part_fix, c->part_list, c->part_counter, over_scratch, (u32)c->lanes, limit));
             continue;
         }
         LadderArgs ap = a;

@@ -27,4 +27,21 @@ int ct_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const 
     return (int)hipGetLastError();
 }
 
+int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit) {
+    hipLaunchKernelGGL(split_counts_kernel<0>, dim3(1), dim3(64), 0, stream, counts, lanes, limit);
+    return (int)hipGetLastError();
+}
+// the overflow ids' tables (whole entries, working limbs: what ScanMem reads), then fixed-base elements + overflow ids in one launch
+int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
+                         u32* over_scratch, u32 lanes, u32 limit) {
+    (void)lanes; (void)limit;
+    LadderArgs ap = a;
+    ap.index = var_list; ap.base = 0; ap.base_dev = counts + 4; ap.n_dev = counts + 5; ap.scratch = over_scratch;
+    hipLaunchKernelGGL((prep_kernel<ENDO, false, LimbSlots>), dim3(prep_grid), dim3(BLOCK), 0, stream, ap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mixed_ct_tail_kernel<0>, dim3(tail_grid), dim3(BLOCK), 0, stream, a, fix_list, var_list, counts, over_scratch);
+    return (int)hipGetLastError();
+}
+
 }  // namespace fq

@@ -106,6 +106,7 @@ struct LadderArgs {
     uint8_t* status;       // DH only
     const u32* index;      // optional: element ids to process (prep_kernel over the variable-base ids of a mixed batch); NULL = identity
     u32 base;              // first position of this launch (chunked large batches)
+    const u32* base_dev;   // optional: added to `base`, read on the device (the overflow part of a list whose split is decided on the device)
     const u32* n_dev;      // optional: element count read on the device (mixed batches: no host round trip)
     const u32* slot_of;    // PREBUILT, optional (mixed batches): per position, the scratch slot of its table or ~0 = `table`
     const u32* table;      // fixed base: 8 x 48 working limbs (global), staged to LDS
@@ -436,11 +437,12 @@ namespace {   // kernels: one private copy per translation unit (their code obje
 // Large variable-base batches, first half: per element, (DH: membership test, cofactor clearing,) table
 // construction into scratch slot `pos`.  Kept apart from the ladder so that the endomorphisms' register
 // appetite (256 VGPRs) does not set the ladder's occupancy.
-template <int ALGO, bool DH>
+template <int ALGO, bool DH, typename SL = PrebuiltSlots>
 __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
     const u32 pos = blockIdx.x * BLOCK + threadIdx.x;
     if (pos >= (a.n_dev ? *a.n_dev : a.n)) return;
-    const u32 id = a.index ? a.index[a.base + pos] : a.base + pos;
+    const u32 first = a.base + (a.base_dev ? *a.base_dev : 0u);
+    const u32 id = a.index ? a.index[first + pos] : first + pos;
     R1 P;
     if (DH) {
         Fe2<1> x = load_fe2(a.points + 8 * (size_t)id), y = load_fe2(a.points + 8 * (size_t)id + 4);
@@ -449,9 +451,9 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
     } else {
         P = load_r1(a.points + 20 * (size_t)id);
     }
-    u32* slot = a.scratch + (size_t)pos * PrebuiltSlots::SLOT;
-    if (ALGO == ENDO) build_table_endo_pipelined<PrebuiltSlots>(P, slot);
-    else build_table_windowed<PrebuiltSlots>(P, slot);
+    u32* slot = a.scratch + (size_t)pos * SL::SLOT;
+    if (ALGO == ENDO) build_table_endo_pipelined<SL>(P, slot);
+    else build_table_windowed<SL>(P, slot);
 }
 
 // ALGO: ENDO / WINDOWED.  SRC: where the table is.  DH: affine in, cofactor clearing, affine out + status.
@@ -635,6 +637,58 @@ __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, con
     }
 }
 
+// Mixed batches in CONSTANT-TIME mode, rounds larger than one generation.  The variable-base ids run through the fused constant-
+// time kernel (table in registers + LDS, one wave per SIMD), whose generations hold exactly `lanes` elements: config 5's 65 550
+// ids would cost a second generation of the whole chip for 14 elements.  split_counts_kernel therefore cuts a small remainder
+// (at most `limit` ids) off the list on the device; prep_kernel<ENDO, false, LimbSlots> builds those ids' tables into scratch, and
+// this kernel -- 128 registers, 1.6 KB of LDS, up to four waves per SIMD -- runs them TOGETHER with the round's fixed-base
+// elements: a wave whose 64 elements are all fixed-base scans the shared table in LDS (as ladder_kernel<ENDO, LDS, CT>), any other
+// wave scans each lane's own table through a per-lane pointer in global memory (every entry read at every step: no address depends
+// on a digit).  Which kind an element is, is public.
+template <int UNIT_ONLY = 0>        // a template so that only the translation unit that launches it carries a copy
+__global__ void split_counts_kernel(u32* counts, u32 lanes, u32 limit) {         // counts: [n_var, n_fix, -, -, fused, over]
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const u32 n_var = counts[0], rem = n_var % lanes, whole = n_var - rem;
+    const bool cut = whole > 0 && rem > 0 && rem <= limit;
+    counts[4] = cut ? whole : n_var;
+    counts[5] = cut ? rem : 0u;
+}
+template <int UNIT_ONLY = 0>
+__global__ __launch_bounds__(BLOCK, 4) void mixed_ct_tail_kernel(LadderArgs a, const u32* fix_list, const u32* var_list, const u32* counts, const u32* over_scratch) {
+    __shared__ __attribute__((aligned(16))) u32 lds_table[8 * LDS_ENTRY_U32];
+    for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
+        lds_table[(i / R2_LIMBS) * LDS_ENTRY_U32 + (i % R2_LIMBS)] = a.table[i];
+    __syncthreads();
+    const u32 n_fix = counts[1], fused = counts[4], total = n_fix + counts[5];
+    const u32 lanes = gridDim.x * BLOCK, n_round = (total + BLOCK - 1) / BLOCK * BLOCK;
+    constexpr int CH = LADDER_CH;
+#pragma unroll 1
+    for (u32 it = blockIdx.x * BLOCK + threadIdx.x; it < n_round; it += lanes) {
+        const bool live = it < total;
+        const u32 pos = live ? it : total - 1;                // idle tail lanes redo the last element, store nothing
+        const bool fixed = pos < n_fix;
+        const u32 id = fixed ? fix_list[pos] : var_list[fused + (pos - n_fix)];
+        u64 m[4], v[4];
+        load_scalar(a.scalars + 4 * (size_t)id, m);
+        decompose(m, v);
+        const EndoDigits e = recode(v);
+        R1 Q;
+        if (__all(fixed)) {                                   // wave-uniform, and public
+            Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
+        } else {
+            const u32* tbl = fixed ? a.table : over_scratch + (size_t)(pos - n_fix) * LimbSlots::SLOT;
+            Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ tbl, LimbSlots::ENTRY });
+        }
+        if (live) {
+            u64 o[20];
+            store_r1(o, Q);
+            uint4* dst = reinterpret_cast<uint4*>(a.out + 20 * (size_t)id);
+#pragma unroll
+            for (int k = 0; k < 10; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
+        }
+    }
+}
+
 // ---- fixed-base comb -------------------------------------------------------------
 constexpr int COMB_POINTS = COMB_POINTS_ALL;                  // 1 024 (by address) + 80 (constant-time mode)
 static_assert(COMB_POINTS == FOURQ_COMB_POINTS, "include/fourq_amd.h and recode.hip.h disagree on the comb's shape");
@@ -787,6 +841,9 @@ int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, con
 int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
 // constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
+                         u32* over_scratch, u32 lanes, u32 limit);     // split_counts_kernel must already have run: see fourq_ct_chain.hip
+int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit);
 int ct_launch_mixed_queue(unsigned grid, hipStream_t stream, const LadderArgs& a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head);
 int ct_launch_lds(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);        // defers when a.proj != NULL
 int ct_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, uint4* proj, u32 proj_stride, u32 n);

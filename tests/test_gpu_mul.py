@@ -183,6 +183,47 @@ def test_full_size_cfg5_mixed_vs_c_oracle(eng):
     assert 0.49 < flags.mean() < 0.51 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("queue", ["0", "1"])
+def test_mixed_batch_on_both_routes(queue, monkeypatch):
+    """A mixed batch through round 2's three launches (FOURQ_MIXED_QUEUE=0) and through the persistent work-queue kernel
+    (FOURQ_MIXED_QUEUE=1: BASELINE config 5's mechanism), both selection modes, ragged item counts of both kinds."""
+    from fourq_amd import Engine
+    monkeypatch.setenv("FOURQ_MIXED_QUEUE", queue)
+    n = 9001
+    s = seeded_scalars(50011, n)
+    flags = (seeded_scalars(50012, n)[:, 0] % 3 == 0).astype(np.uint8)              # a third variable-base
+    with Engine(0) as e:
+        pts = torsion_points(e, 50013, n)
+        tbl = e.table_endo(codec.pack_point(G1))
+        want = np.where(flags[:, None] == 0, oc.mul(oc.ENDO, s, None, tbl), oc.mul(oc.ENDO, s, pts))
+        for ct in (False, True):
+            e.ct_select = ct
+            assert np.array_equal(e.mul_endo_mixed(s, pts, flags, tbl), want), (queue, ct)
+            for m in (1, 63, 64, 65):                                              # fewer elements than one work item / exactly one / one more
+                assert np.array_equal(e.mul_endo_mixed(s[:m], pts[:m], flags[:m], tbl), want[:m]), (queue, ct, m)
+
+
+@pytest.mark.parametrize("extra", [0, 300, 9000])
+def test_constant_time_mixed_round_cuts_a_small_remainder_off_the_fused_generations(extra):
+    """Constant-time mode, a round larger than one generation: the variable-base ids past whole generations of the fused kernel
+    ride with the fixed-base elements when there are at most lanes / 8 of them (mixed_ct_tail_kernel); 0 ids: nothing to cut,
+    9 000: too many, a second fused generation.  Every output against the C oracle."""
+    from fourq_amd import Engine
+    with Engine(0) as e:
+        e.ct_select = True
+        n_var, n_fix = e.lanes + extra, 3000
+        n = n_var + n_fix
+        flags = np.ones(n, dtype=np.uint8)
+        flags[np.random.RandomState(7).choice(n, n_fix, replace=False)] = 0         # the fixed-base elements scattered through the batch
+        s = seeded_scalars(50021 + extra, n)
+        pts = torsion_points(e, 50023, n)
+        tbl = e.table_endo(codec.pack_point(G1))
+        want = oc.mul(oc.ENDO, s, pts)
+        fix = np.flatnonzero(flags == 0)
+        want[fix] = oc.mul(oc.ENDO, s[fix], None, tbl)
+        assert np.array_equal(e.mul_endo_mixed(s, pts, flags, tbl), want)
+
+
 @pytest.mark.parametrize("n", [131071, 131072, 262144 + 77])
 def test_prep_plus_ladder_route_boundaries(n, monkeypatch):
     """Large variable-base MUL_windowed / DH batches take the two-kernel route (prep_kernel +

@@ -227,7 +227,7 @@ def audit_units(units, tmp=None):
         if p.wait() != 0:
             raise SystemExit("hipcc failed on %s" % u)
         for name, body in kernels(open(out).read().splitlines()):
-            if "ladder_kernel" not in name and "comb_kernel" not in name and "mixed_queue_kernel" not in name:
+            if not any(k in name for k in ("ladder_kernel", "comb_kernel", "mixed_queue_kernel", "mixed_ct_tail_kernel")):
                 continue
             checked, bad = audit_kernel(name, body)
             rows.append((u, name, checked, len(bad)))
