@@ -404,24 +404,11 @@ template <typename L, typename P> FQ_DEV void store_r2(P* dst, const R2& t) {
 // N and D of +-T for a table entry T: R2neg(T) = (D, N, E, -F) (curve4q.py:193-206).  Both coordinates are read from
 // their own addresses whatever the sign is and exchanged by masked selects -- GFp2.select of fields.py:236-238, one
 // v_bitop3_b32 per limb -- exactly as the reference's selectpt does: the sign of a digit never becomes an address.
-// (FQ_SIGN_BY_ADDRESS=1 restores round 2's address choice for A/B measurements only.)
-#ifndef FQ_SIGN_BY_ADDRESS
-#define FQ_SIGN_BY_ADDRESS 0
-#endif
+// (Round 2 chose by address; the A/B of the two is profiles/r03_sign_select.txt, the switch tools/experiments/r03_sign_by_address.patch.)
 template <typename LOAD> FQ_DEV void load_signed_nd(LOAD load, int coord, u32 neg_mask, Fe2<1>& N, Fe2<1>& D) {
-#if FQ_SIGN_BY_ADDRESS
-    const int off_n = neg_mask ? coord : 0, off_d = neg_mask ? 0 : coord;
-    N = load(off_n); D = load(off_d);
-#else
     const Fe2<1> n = load(0), d = load(coord);
-#if defined(FQ_SIGN_SELECT_XOR)      // A/B only: the xor form, which hipcc turns into three instructions per limb pair
-    N = fe2_select(neg_mask, d, n);
-    D = fe2_select(neg_mask, n, d);
-#else
     N = fe2_bitselect(neg_mask, d, n);
     D = fe2_bitselect(neg_mask, n, d);
-#endif
-#endif
 }
 template <int CH, int A, int B> FQ_DEV auto fe2_subx(const Fe2<A>& a, const Fe2<B>& b) {
     if constexpr (CH == 2) return widen<A + B + 1>(fe2_sub_signed(a, b)); else return fe2_sub(a, b);
@@ -463,11 +450,8 @@ struct EntryRegs {
 // `ef` (kernels.hip.h: LdsEF / NoEF): where E and F come from -- the entry itself, or the lane's copy of them in LDS
 template <typename L = LimbSlots, typename P, typename EF> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask, u32 digit, const EF& ef) {
     EntryRegs t;
-#if FQ_SIGN_BY_ADDRESS
-    load_signed_nd([&](int off) { return L::load(entry + off); }, L::COORD, neg_mask, t.N, t.D);
-#else
+    (void)neg_mask;
     t.N = L::load(entry); t.D = L::load(entry + L::COORD);          // the sign is applied by add_entry, behind the doubling
-#endif
     if constexpr (EF::ON) {
         t.E = ef.get(digit, 0); t.F = ef.get(digit, 1);
     } else {
@@ -476,16 +460,11 @@ template <typename L = LimbSlots, typename P, typename EF> FQ_DEV EntryRegs load
     return t;
 }
 template <int CH> FQ_DEV R1 add_entry(const R1& q, const EntryRegs& t, u32 neg_mask) {
-#if FQ_SIGN_BY_ADDRESS
-    const Fe2<1>& tN = t.N;
-    const Fe2<1>& tD = t.D;
-#else
     // The masked exchange of N and D must not be scheduled next to the gathers (hipcc does that when it may, and the lone
     // wave then sits out the gather latency at the top of every step: measured -7 % on the headline kernel).  The mask is
     // made to depend on the doubled point, so the twenty selects can only issue once the doubling has been computed.
     asm("" : "+v"(neg_mask) : "v"(q.X.re.l[0]), "v"(q.Y.re.l[0]), "v"(q.Z.re.l[0]));
     const Fe2<1> tN = fe2_bitselect(neg_mask, t.D, t.N), tD = fe2_bitselect(neg_mask, t.N, t.D);
-#endif
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
