@@ -79,9 +79,10 @@ def seeded_flags(seed, n):
     return (np.frombuffer(random.Random(seed).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
 
 
-def host_cores():
+def host_cores(cap=True):
     """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (the GPU
-    box shows every core of the host but grants a 16-core share per GPU)."""
+    box shows every core of the host but grants a 16-core share per GPU).  cap=False: without the 16-core ceiling of
+    one rank's share (the ranks of an N-GPU job divide what the whole job was granted)."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
@@ -99,7 +100,7 @@ def host_cores():
             break
         except (OSError, ValueError, IndexError):
             continue
-    return min(cores, int(os.environ.get("FOURQ_BENCH_CORES", "16")))
+    return min(cores, int(os.environ.get("FOURQ_BENCH_CORES", "16"))) if cap else cores
 
 
 # ---- CPU baseline (the oracle is the checker and the thing timed here, never part of the GPU path) --------------
@@ -171,7 +172,7 @@ def c_oracle_gate(workload, data, got_words, world=1):
     import numpy as np
     import oracle_c as oc
     from fourq_amd import codec, constants
-    share = max(1, host_cores() // max(1, world))
+    share = host_cores() if world <= 1 else max(1, min(host_cores(), host_cores(cap=False) // world))
     threads = oc.set_num_threads(share)
     assert threads == share, "OpenMP did not take the thread count"
     s, k = data["scalars_h"], data["second_h"]
@@ -559,7 +560,7 @@ def self_launch(args, argv):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(host_cores(), host_cores(cap=False) // args.gpus))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     # stdout carries rank 0's JSON line and nothing else: whatever the ranks' libraries print there (gloo's connection

@@ -92,4 +92,18 @@ with Engine(0) as eng:
         ok = np.array_equal(x, cpu())
         print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  identical=%s" % (name, LG, t1 - t0, ok), flush=True)
         assert ok
+    # round 3: the mixed batch in constant-time mode (fused generations + the tail kernel with its riders), and both GPUs' worth of contexts behind one call
+    t0 = time.time(); a = eng.mul_endo_mixed(s, pts, flags, te); t1 = time.time()
+    want_mixed = np.where(flags.reshape(-1, 1) != 0, ref, oc.mul(oc.ENDO, s, None, te))
+    print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  identical=%s" % ("mixed 50/50, constant-time", LG, t1 - t0, np.array_equal(a, want_mixed)), flush=True)
+    assert np.array_equal(a, want_mixed)
+from fourq_amd import MultiEngine
+with MultiEngine([0, 0]) as multi:
+    t0 = time.time(); a = multi.mul_endo(s, pts); t1 = time.time()
+    print("%-28s n=2^%d  GPU %.2fs (PCIe incl.)  identical=%s" % ("MultiEngine([0, 0]).mul_endo", LG, t1 - t0, np.array_equal(a, ref)), flush=True)
+    assert np.array_equal(a, ref)
+    a, sa = multi.dh_exchange(k2, s, codec.pack_point((o.Gx, o.Gy)))
+    ok = not sa.any() and np.array_equal(a, want)
+    print("%-28s n=2^%d  identical=%s" % ("MultiEngine dh_exchange", LG, ok), flush=True)
+    assert ok
 print("SOAK OK")
