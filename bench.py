@@ -448,7 +448,7 @@ class Bench:
         import numpy as np
         eng = self.eng
         n = len(d["scalars_h"])
-        pins = []
+        pins, extra = [], {}
 
         def pin(a):
             pins.append(eng.host_array(a))
@@ -480,13 +480,22 @@ class Bench:
                     raise SystemExit("cfg4 host-array path: unexpected DH failure status")
                 return out
             calls = {"pinned": lambda: exchange(a_pin, b_pin, o_pin, st_pin), "pageable": lambda: exchange(d["scalars_h"], d["second_h"], None, None)}
+
+            def exchange_comb(a, b, o, st):        # the keygen half through the staged comb: bench's cfg4 step as ONE host-array call
+                out, status = eng.dh_exchange_comb(a, b, None, out=o, status=st)
+                if status.any():
+                    raise SystemExit("cfg4 host-array path (comb): unexpected DH failure status")
+                return out
+            extra = {"keygen_through_the_comb (fourq_dh_exchange_comb_batch, pinned)": lambda: exchange_comb(a_pin, b_pin, o_pin, st_pin)}
         else:
             io, bytes_in, bytes_out = "scalar + R1 + flag in / R1 out (fourq_mul_endo_mixed_batch)", 193, 160
             s_pin, p_pin, f_pin, o_pin = pin(d["scalars_h"]), pin(d["points_h"]), pin(d["flags_h"]), pin_empty((n, 20))
             calls = {"pinned": lambda: eng.mul_endo_mixed(s_pin, p_pin, f_pin, d["table_h"], out=o_pin),
                      "pageable": lambda: eng.mul_endo_mixed(d["scalars_h"], d["points_h"], d["flags_h"], d["table_h"])}
         rec = {"io": "%s: %d B in + %d B out per unit" % (io, bytes_in, bytes_out), "batch": n, "reps": reps}
-        for label in ("pinned", "pageable"):
+        if workload == "cfg4":
+            calls.update(extra)
+        for label in calls:
             call = calls[label]
             call()                                              # sizes the pipeline's buffers
             t0 = time.perf_counter()
@@ -500,8 +509,10 @@ class Bench:
                  "chunks": st["chunks"], "wall_gbs_both_directions": round(n * (bytes_in + bytes_out) / dt / 1e9, 2)}
             if label == "pinned":
                 rec.update(r)
-            else:
+            elif label == "pageable":
                 rec["pageable_caller"] = r
+            else:
+                rec[label.split(" ")[0]] = dict(r, call=label)
         rec["note"] = ("value = units / wall-clock of the synchronous host-array call (H2D, kernels, D2H pipelined over chunks of whole "
                        "kernel generations); gbs_* = bytes / summed copy durations (HIP events on the copy streams), i.e. the link rate while a "
                        "copy is running; every output compared with the C oracle")

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "fourq_dh_windowed_bytes_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_exchange_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_dh_exchange_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_exchange_comb_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_dh_exchange_comb_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_comb_table": (c_int, [c_void_p, c_void_p, c_void_p]),
     "fourq_comb_stage": (c_int, [c_void_p, c_void_p]),
     "fourq_comb_mul_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),

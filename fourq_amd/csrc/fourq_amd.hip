@@ -1235,6 +1235,36 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
     });
 }
 
+// dh_exchange with the key-generation half through the comb (bench.py's cfg4 step as one call)
+FQ_API int fourq_dh_exchange_comb_batch_dev(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
+    if (!c || !a || !b || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;
+    if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    int rc = ensure_work(c, exchange_work_bytes(n));
+    if (rc) return rc;
+    uint64_t* mid = (uint64_t*)(c->work + n * 64);            // [b_i]B: the public keys (same place as in fourq_dh_exchange_batch_dev)
+    uint8_t* st_first = (uint8_t*)(c->work + 2 * n * 64);
+    if ((rc = fourq_comb_mul_batch_dev(c, b, comb, mid, st_first, n))) return rc;
+    if ((rc = dh_dev(c, ENDO, a, mid, nullptr, out, status, n))) return rc;
+    hipLaunchKernelGGL(merge_status_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, st_first, status, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
+    if (!c || !a || !b || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    DeviceGuard g(c->device);
+    if (comb) { int rc = stage_comb(c, comb); if (rc) return rc; }          // compared once, not once per chunk
+    PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
+    PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
+    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+        return fourq_dh_exchange_comb_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], nullptr, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
+    });
+}
+
 // ---- pinned host memory and transfer statistics of the host-pointer calls ---------------------------------------
 FQ_API int fourq_host_alloc(fourq_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return FOURQ_ERR_INVALID;

@@ -239,6 +239,26 @@ class Engine:
         self._ck(self._lib.fourq_dh_exchange_batch(self._ctx, _ptr(a), _ptr(b), _ptr(base), _ptr(t), _ptr(out), _ptr(status), len(a)))
         return out, status
 
+    def dh_exchange_comb(self, a_scalars, b_scalars, comb=None, out=None, status=None):
+        """One exchange per row with the key-generation half through the comb of [392]base (fourq_dh_exchange_comb_batch):
+        DH_endo(a_i, DH_endo(b_i, base)) -- same outputs as dh_exchange, the first half 3x cheaper.  `comb`: a comb table
+        (comb_table([392]base)) or None = the table staged by comb_stage().  Returns (affine, status)."""
+        a, b = _host(a_scalars, 4), _host(b_scalars, 4)
+        if len(a) != len(b):
+            raise ValueError("the two scalar arrays differ in length")
+        t = None
+        if comb is not None:
+            t = _host(comb, None).ravel()
+            if t.size != _lib.COMB_WORDS:
+                raise ValueError("a comb table is %d words" % _lib.COMB_WORDS)
+        out, status = _out(out, len(a), 8), _out(status, len(a), None, np.uint8)
+        self._ck(self._lib.fourq_dh_exchange_comb_batch(self._ctx, _ptr(a), _ptr(b), _ptr(t), _ptr(out), _ptr(status), len(a)))
+        return out, status
+
+    def dh_exchange_comb_dev(self, a_scalars, b_scalars, comb_host, out_affine, status, n):
+        t = None if comb_host is None else _host(comb_host, None).ravel()
+        self._ck(self._lib.fourq_dh_exchange_comb_batch_dev(self._ctx, _ptr(a_scalars), _ptr(b_scalars), _ptr(t), _ptr(out_affine), _ptr(status), n))
+
     def dh_exchange_dev(self, a_scalars, b_scalars, base_affine_host, table392_host, out_affine, status, n):
         base = _host(base_affine_host, None).ravel()
         t = None if table392_host is None else _host(table392_host, None).ravel()

@@ -157,6 +157,12 @@ class MultiEngine:
         return self._sharded(lambda e, a, b, o, st: e.dh_exchange(a, b, base_affine, table392, out=o, status=st), [a, b],
                              [_out(out, len(a), 8), _out(status, len(a), None, np.uint8)])
 
+    def dh_exchange_comb(self, a_scalars, b_scalars, comb, out=None, status=None):
+        a, b = _host(a_scalars, 4), _host(b_scalars, 4)
+        self._same_len(a, b)
+        return self._sharded(lambda e, a, b, o, st: e.dh_exchange_comb(a, b, comb, out=o, status=st), [a, b],
+                             [_out(out, len(a), 8), _out(status, len(a), None, np.uint8)])
+
     def comb_mul(self, scalars, comb, out=None, status=None):
         s = _host(scalars, 4)
         return self._sharded(lambda e, s, o, st: e.comb_mul(s, comb, out=o, status=st), [s],

@@ -213,6 +213,14 @@ int fourq_comb_stage(fourq_ctx *ctx, const uint64_t *comb);
 /* status[i]: FOURQ_DH_OK or FOURQ_DH_NEUTRAL ([m]B is the neutral point); out zeroed in that case */
 int fourq_comb_mul_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *comb, uint64_t *out_affine, uint8_t *status, size_t n);
 int fourq_comb_mul_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *comb, uint64_t *out_affine, uint8_t *status, size_t n);
+/* One exchange per element with the key-generation half through the comb: out[i] = DH_endo(a_i, K_i) with
+ * K_i = [b_i]B affine = DH_endo(b_i, base, table_endo([392]base)) for the comb of B = [392]base (draft :725-729: any method
+ * that agrees) -- BASELINE.json "dh_exchange" as bench.py's cfg4 runs it, as ONE call; the public keys K stay on the device.
+ * `comb` as in fourq_comb_mul_batch (NULL = the staged table).  status[i]: first failure of either half. */
+int fourq_dh_exchange_comb_batch(fourq_ctx *ctx, const uint64_t *a_scalars, const uint64_t *b_scalars, const uint64_t *comb,
+                                 uint64_t *out_affine, uint8_t *status, size_t n);
+int fourq_dh_exchange_comb_batch_dev(fourq_ctx *ctx, const uint64_t *a_scalars, const uint64_t *b_scalars, const uint64_t *comb,
+                                     uint64_t *out_affine, uint8_t *status, size_t n);
 
 /* ---- primitives (one reference function per op, batched) --------------------------------------
  * Used by the Python mirror of the reference's helper API (GFp.*, GFp2.*, DBL, ADD, phi, ...) and by

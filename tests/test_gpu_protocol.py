@@ -129,6 +129,19 @@ def test_dh_exchange_on_device(eng, golden):
     bad = codec.pack_point(((1, 2), (3, 4)))  # base not on the curve: every exchange is rejected at the first step
     out, st = eng.dh_exchange(a[:8], b[:8], bad)
     assert (st == _lib.DH_NOT_ON_CURVE).all() and not out.any()
+    # the same exchanges with the key-generation half through the comb of [392]G (fourq_dh_exchange_comb_batch): same outputs, same verdicts
+    comb = eng.comb_table(codec.pack_point(o.MUL_endo(392, G1)))
+    out_c, st_c = eng.dh_exchange_comb(a, b, comb)
+    assert np.array_equal(st_c, ws) and np.array_equal(out_c, want)
+    eng.comb_stage(comb)
+    out_c, st_c = eng.dh_exchange_comb(a[:100], b[:100])            # None = the staged comb
+    assert np.array_equal(st_c, ws[:100]) and np.array_equal(out_c, want[:100])
+    m = 2 * eng.lanes + 321                                          # several pipeline chunks, the two-kernel route in the second half
+    a2, b2 = seeded_scalars(33, m), seeded_scalars(34, m)
+    out_c, st_c = eng.dh_exchange_comb(a2, b2)
+    mid, s1 = oc.dh(oc.ENDO, b2, np.repeat(codec.pack_point(G).reshape(1, 8), m, axis=0))
+    want2, s2 = oc.dh(oc.ENDO, a2, mid)
+    assert not s1.any() and not s2.any() and not st_c.any() and np.array_equal(out_c, want2)
 
 
 @pytest.mark.parametrize("pinned", [False, True])
