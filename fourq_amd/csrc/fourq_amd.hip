@@ -344,6 +344,7 @@ struct fourq_ctx {
     u32* part_fix = nullptr;       // constant-time mode: ids of the round's fixed-base elements
     bool ct = false;               // constant-time table selection (FOURQ_CT_SELECT / fourq_ctx_set_ct_select)
     int mixed_queue = -1;          // mixed batches through the persistent work-queue kernel: 1 always, 0 never, -1 = where it measured faster
+    size_t pair_max = 0;           // plain MUL_endo: batches (and tails past whole generations) of at most this many elements run two lanes per element
     uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
     size_t proj_capacity = 0;
     int norm_k = -1;               // FOURQ_NORM_K: 0 = always invert per element, 2/4/8 = always batch; -1 = by batch size
@@ -422,7 +423,27 @@ bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
     if (algo == WINDOWED || dh || c->split_all) return n >= c->split_min;
     return c->split_endo_min && n >= c->split_endo_min;
 }
+// Plain variable-base MUL_endo, two lanes per element (pair.hip.h): 0.58 of the one-lane kernel's latency for at most half a
+// generation of elements.  A batch that small runs on it alone; a batch of q generations + r elements, 0 < r <= pair_max, runs
+// q fused generations and then the r elements on it, so the element past a generation costs 0.6 of a generation instead of one.
+int launch_pair_endo(fourq_ctx* c, LadderArgs a) {
+    if (a.n == 0) return FOURQ_OK;
+    const size_t blocks = ((size_t)a.n + BLOCK / 2 - 1) / (BLOCK / 2);
+    hipLaunchKernelGGL(pair_mul_endo_kernel<0>, dim3((unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus)), dim3(BLOCK), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
 template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
+    if (ALGO == ENDO && !DH && !c->ct && !a.index && c->pair_max && !takes_split_route(c, ALGO, DH, a.n)) {
+        const u32 tail = (u32)(a.n % c->lanes);
+        if (tail != 0 && tail <= c->pair_max) {
+            LadderArgs whole = a, rest = a;
+            whole.n = a.n - tail;
+            rest.base = a.base + whole.n; rest.n = tail;
+            int rc = whole.n ? launch_ladder<ALGO, FUSED, DH>(c, whole) : FOURQ_OK;
+            return rc ? rc : launch_pair_endo(c, rest);
+        }
+    }
     if (!takes_split_route(c, ALGO, DH, a.n)) return launch_ladder<ALGO, FUSED, DH>(c, a);
     const u32 total = a.n;
     for (u32 off = 0; off < total; off += (u32)c->split_chunk) {
@@ -806,6 +827,8 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = getenv("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
+        c->pair_max = c->lanes / 2;                        // two lanes per element: half a generation fills the chip
+        if (const char* env = getenv("FOURQ_PAIR_MAX")) { long v = atol(env); if (v >= 0 && (size_t)v <= c->lanes / 2) c->pair_max = (size_t)v; }
         if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
         c->split_chunk = c->lanes_w4;
         if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }

@@ -1,0 +1,333 @@
+// Two lanes per element: variable-base MUL_endo for SMALL batches and for the tail of a batch past whole generations.
+//
+// One lane owns one scalar multiplication for 0.33 ms of dependent instructions however few lanes are busy (DESIGN.md section 9:
+// the generation cliff), so a batch of 100 elements and the 256 elements past a full generation each cost what 65 536 cost.
+// Here lane 2k holds the REAL parts and lane 2k + 1 the IMAGINARY parts of every GF(p^2) value of element k (each a GF(p)
+// element: 5 signed 26-bit limbs).  Additions are limb-wise on the lane's half; a product a*b is one sum of two GF(p) products
+// per lane -- even lane: a_re*b_re + (-a_im)*b_im, odd lane: a_im*b_re + a_re*b_im -- with the partner's halves fetched by
+// v_mov_b32_dpp quad_perm (no LDS, no waits); a square is one GF(p) product per lane.  A lane issues 1 323 instead of 2 133
+// instructions per ladder step (tools/microbench/pairlane.hip: 0.58 of the step's latency at one wave per SIMD; at two waves
+// per SIMD, i.e. the same elements per chip, it is within +-3 % of the one-lane step, so it is no throughput lever).
+//
+// Same formula DAG as curve.hip.h (curve4q.py:109-175, :258-322, :385-442), hence the same residues in the R1 tuple.  Signed
+// flavour throughout (fp127.hip.h): every element type carries the bound B of its limb magnitudes and every product static_asserts
+// its operand and column bounds, as the one-lane code does.
+#pragma once
+#include "curve.hip.h"
+#include "recode.hip.h"
+
+namespace fq {
+
+template <int B> struct PF { u32 l[5]; };          // this lane's half of a GF(p^2) value, |limb| <= B * UNIT
+struct PairLane { u32 even, odd_neg; };            // even = ~0 on lanes holding real parts; odd_neg = ~0 on lanes holding imaginary parts
+
+template <int B2, int B> FQ_DEV PF<B2> pwiden(const PF<B>& a) {
+    static_assert(B2 >= B, "cannot narrow a bound");
+    PF<B2> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i];
+    return r;
+}
+template <int A, int B> FQ_DEV PF<A + B> padd(const PF<A>& a, const PF<B>& b) {
+    static_assert((u64)(A + B) * UNIT < (1ull << 31), "limb overflow");
+    PF<A + B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+template <int A, int B> FQ_DEV PF<A + B> psub(const PF<A>& a, const PF<B>& b) {
+    static_assert((u64)(A + B) * UNIT < (1ull << 31), "limb overflow");
+    PF<A + B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+template <int B> FQ_DEV PF<2 * B> pdbl(const PF<B>& a) { return padd(a, a); }
+template <int B> FQ_DEV PF<B> pcneg(const PF<B>& a, u32 m) {      // -a where m == ~0
+    PF<B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = (a.l[i] ^ m) - m;
+    return r;
+}
+template <int B> FQ_DEV PF<B> pneg(const PF<B>& a) { return pcneg(a, ~0u); }
+template <int B> FQ_DEV PF<B> pconj(const PF<B>& a, const PairLane& pl) { return pcneg(a, pl.odd_neg); }   // fields.py:189-191
+
+constexpr int DPP_SWAP = 0xB1, DPP_EVEN = 0xA0, DPP_ODD = 0xF5;      // quad_perm [1,0,3,2], [0,0,2,2], [1,1,3,3]
+template <int CTRL, int B> FQ_DEV PF<B> pdpp(const PF<B>& a) {
+    PF<B> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)a.l[i], CTRL, 0xF, 0xF, true);
+    return r;
+}
+#define FQ_POPAQUE(x) asm("" : "+v"(x))
+// A lane has ONE result column at a time (its partner has the other), so chained multiply-adds would follow each other back to
+// back -- and behind every opaque partial sum hipcc pads an s_nop before the next instruction that reads it (467 per ladder step
+// measured, a third of the step's issue slots).  Each column is therefore accumulated in TWO chains that alternate (u*v in one,
+// w*z in the other; a square's products by parity) and are added once per column: +5 64-bit additions per product, -400 s_nop per step.
+#ifndef FQ_PAIR_CHAINS
+#define FQ_PAIR_CHAINS 2
+#endif
+// r = u*v + w*z (one component of a GF(p^2) product), signed limbs, carries chained: the column loop of fe2_mul_signed
+template <int U, int V> FQ_DEV PF<1> pmac2(const u32 u[5], const u32 v[5], const u32 w[5], const u32 z[5]) {
+    static_assert(cols_ok_signed((u64)2 * U * V), "column overflow");
+    static_assert(fits8_signed<V>(), "8*v does not fit a signed 32-bit operand: swap the operands");
+    u32 v8[5], z8[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { v8[i] = v[i] << 3; z8[i] = z[i] << 3; }
+    u32 l[5];
+    i64 acc = 0;
+#pragma unroll
+    for (int K = 0; K < 5; K++) {
+        i64 side = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int j = K - i;
+            acc += smul(u[i], j >= 0 ? v[j >= 0 ? j : 0] : v8[j >= 0 ? 0 : j + 5]); FQ_POPAQUE(acc);
+            if (FQ_PAIR_CHAINS == 2) { side += smul(w[i], j >= 0 ? z[j >= 0 ? j : 0] : z8[j >= 0 ? 0 : j + 5]); FQ_POPAQUE(side); }
+            else { acc += smul(w[i], j >= 0 ? z[j >= 0 ? j : 0] : z8[j >= 0 ? 0 : j + 5]); FQ_POPAQUE(acc); }
+        }
+        if (FQ_PAIR_CHAINS == 2) acc += side;
+        l[K] = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    }
+    const Fe<1> f = fe_finish_signed(l[0], l[1], l[2], l[3], l[4], acc);
+    PF<1> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = f.l[i];
+    return r;
+}
+// a * b.  even lane: re = a_re*b_re - a_im*b_im ; odd lane: im = a_im*b_re + a_re*b_im: in both, u = this lane's half of a,
+// v = b_re, w = the partner's half of a (negated on even lanes), z = b_im.  The operand whose 8-fold must fit 32 bits is b: when
+// only a's does, the (commutative) product is taken the other way round.
+template <int A, int B> FQ_DEV PF<1> pmul(const PF<A>& a, const PF<B>& b, const PairLane& pl) {
+    if constexpr (!fits8_signed<B>() && fits8_signed<A>()) {
+        return pmul(b, a, pl);
+    } else {
+        const PF<A> w = pcneg(pdpp<DPP_SWAP>(a), pl.even);
+        const PF<B> v = pdpp<DPP_EVEN>(b), z = pdpp<DPP_ODD>(b);
+        return pmac2<A, B>(a.l, v.l, w.l, z.l);
+    }
+}
+// a * c for a curve constant c: both halves of c are literals, no exchange for them
+template <int A> FQ_DEV PF<1> pmul_const(const PF<A>& a, const Fe2<1>& c, const PairLane& pl) {
+    const PF<A> w = pcneg(pdpp<DPP_SWAP>(a), pl.even);
+    u32 v[5], z[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { v[i] = c.re.l[i]; z[i] = c.im.l[i]; FQ_SIGN_UNKNOWN(v[i]); FQ_SIGN_UNKNOWN(z[i]); }
+    return pmac2<A, 1>(a.l, v, w.l, z);
+}
+// a^2.  even lane: (a_re + a_im)(a_re - a_im) ; odd lane: (2 a_re) a_im: one GF(p) product u*v per lane      fields.py:176-181
+template <int A> FQ_DEV PF<1> psqr(const PF<A>& a, const PairLane& pl) {
+    static_assert((u64)2 * A * UNIT < (1ull << 31), "limb overflow");
+    static_assert(cols_ok_signed((u64)(2 * A) * (2 * A)), "column overflow");
+    const PF<A> o = pdpp<DPP_SWAP>(a);
+    u32 u[5], v[5], uw[5], vw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        u[i] = o.l[i] + __builtin_amdgcn_bitop3_b32(pl.even, a.l[i], o.l[i], 0xCA);      // even: a + o ; odd: 2 o      (bound 2A)
+        v[i] = a.l[i] - (o.l[i] & pl.even);                                              // even: a - o ; odd: a        (bound 2A)
+    }
+    constexpr bool WIDE = !fits8_signed<2 * A>();            // 8*v would not fit: the wrap-around factor 8 as (4u)(2v), as wrap_operands_signed
+    static_assert(!WIDE || ((u64)4 * 2 * A * UNIT < (1ull << 31)), "no split of the factor 8 fits");
+#pragma unroll
+    for (int i = 0; i < 5; i++) { vw[i] = v[i] << (WIDE ? 1 : 3); uw[i] = WIDE ? u[i] << 2 : u[i]; }
+    u32 l[5];
+    i64 acc = 0;
+#pragma unroll
+    for (int K = 0; K < 5; K++) {
+        i64 side = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int j = K - i;
+            const i64 prod = smul(j >= 0 ? u[i] : uw[i], j >= 0 ? v[j >= 0 ? j : 0] : vw[j >= 0 ? 0 : j + 5]);
+            if (FQ_PAIR_CHAINS == 2 && (i & 1)) { side += prod; FQ_POPAQUE(side); }
+            else { acc += prod; FQ_POPAQUE(acc); }
+        }
+        if (FQ_PAIR_CHAINS == 2) acc += side;
+        l[K] = (u32)acc & LIMB_MASK; acc >>= LIMB_BITS;
+    }
+    const Fe<1> f = fe_finish_signed(l[0], l[1], l[2], l[3], l[4], acc);
+    PF<1> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = f.l[i];
+    return r;
+}
+#undef FQ_POPAQUE
+
+// ---- points (halves) -------------------------------------------------------------------------------------------------
+struct PR1 { PF<1> X, Y, Z; PF<3> Ta; PF<2> Tb; };      // (X, Y, Z, Ta, Tb)
+struct PR2 { PF<2> N, D, E; PF<1> F; };                 // (X+Y, Y-X, 2Z, 2dT): a table entry
+struct PR3 { PF<2> N, D; PF<1> E, F; };                 // (X+Y, Y-X, Z, T)
+struct PProj { PF<1> X, Y, Z; };
+
+FQ_DEV PR2 pr1_to_r2(const PR1& p, const PairLane& pl) {                                    // curve4q.py:109-116
+    PR2 r;
+    r.N = padd(p.X, p.Y); r.D = psub(p.Y, p.X); r.E = pdbl(p.Z);
+    r.F = pmul_const(pmul(p.Ta, p.Tb, pl), fe2_two_d(), pl);
+    return r;
+}
+FQ_DEV PR3 pr1_to_r3(const PR1& p, const PairLane& pl) {                                    // curve4q.py:119-126
+    PR3 r;
+    r.N = padd(p.X, p.Y); r.D = psub(p.Y, p.X); r.E = p.Z; r.F = pmul(p.Ta, p.Tb, pl);
+    return r;
+}
+FQ_DEV PR1 pdbl_point(const PF<1>& X, const PF<1>& Y, const PF<1>& Z, const PairLane& pl) {  // curve4q.py:138-152 (the signed DAG of curve.hip.h)
+    const PF<1> A = psqr(X, pl), B = psqr(Y, pl);
+    const PF<2> C = pdbl(psqr(Z, pl));
+    const PF<2> D = padd(A, B);
+    const PF<3> E = psub(psqr(padd(X, Y), pl), D);
+    const PF<2> F = psub(B, A);
+    const PF<4> G = psub(C, F);
+    PR1 r;
+    r.X = pmul(G, E, pl); r.Z = pmul(G, F, pl); r.Y = pmul(D, F, pl);
+    r.Ta = E; r.Tb = D;
+    return r;
+}
+FQ_DEV PR1 padd_core(const PR3& p, const PR2& q, const PairLane& pl) {                       // curve4q.py:155-171
+    const PF<1> A = pmul(p.D, q.D, pl), B = pmul(p.N, q.N, pl), C = pmul(q.F, p.F, pl), D = pmul(q.E, p.E, pl);
+    const PF<2> E = psub(B, A), F = psub(D, C), G = padd(D, C), H = padd(B, A);
+    PR1 r;
+    r.X = pmul(E, F, pl); r.Y = pmul(G, H, pl); r.Z = pmul(F, G, pl);
+    r.Ta = pwiden<3>(E); r.Tb = H;
+    return r;
+}
+FQ_DEV PProj ptau(const PF<1>& X, const PF<1>& Y, const PF<1>& Z, const PairLane& pl) {      // curve4q.py:258-267
+    const PF<1> A = psqr(X, pl), B = psqr(Y, pl);
+    const PF<2> C = padd(A, B), D = psub(A, B);
+    PProj r;
+    r.X = pmul(D, pmul(Y, pmul_const(X, c_tau(), pl), pl), pl);
+    r.Y = pneg(pmul(padd(pdbl(psqr(Z, pl)), D), C, pl));
+    r.Z = pmul(D, C, pl);
+    return r;
+}
+FQ_DEV PR1 ptau_dual(const PF<1>& X, const PF<1>& Y, const PF<1>& Z, const PairLane& pl) {   // curve4q.py:269-280
+    const PF<1> A = psqr(X, pl), B = psqr(Y, pl);
+    const PF<2> C = padd(A, B), Ta = psub(B, A);
+    const PF<4> D = psub(pdbl(psqr(Z, pl)), Ta);
+    const PF<1> Tb = pmul(Y, pmul_const(X, c_taudual(), pl), pl);
+    PR1 r;
+    r.X = pmul(C, Tb, pl); r.Y = pmul(D, Ta, pl); r.Z = pmul(D, C, pl);
+    r.Ta = pwiden<3>(Ta); r.Tb = pwiden<2>(Tb);
+    return r;
+}
+FQ_DEV PProj pupsilon(const PProj& p, const PairLane& pl) {                                  // curve4q.py:282-302
+    const PF<1> A = pmul(p.Y, pmul_const(p.X, c_phi<0>(), pl), pl), B = pmul(p.Y, p.Z, pl);
+    const PF<1> C = psqr(p.Y, pl), D = psqr(p.Z, pl);
+    const PF<1> F = psqr(D, pl), G = psqr(B, pl), H = psqr(C, pl);
+    const PF<1> I = pmul_const(B, c_phi<1>(), pl);
+    const PF<2> J = padd(C, pmul_const(D, c_phi<2>(), pl));
+    const PF<3> K = padd(padd(pmul_const(G, c_phi<8>(), pl), H), pmul_const(F, c_phi<9>(), pl));
+    const PF<1> x2 = pmul(psub(I, J), padd(I, J), pl);
+    const PF<2> L = padd(C, pmul_const(D, c_phi<4>(), pl));
+    const PF<1> M = pmul_const(B, c_phi<3>(), pl);
+    const PF<1> Nn = pmul(psub(L, M), padd(L, M), pl);
+    const PF<3> y2 = padd(padd(H, pmul_const(G, c_phi<6>(), pl)), pmul_const(F, c_phi<7>(), pl));
+    PProj r;
+    r.X = pconj(pmul(pmul(K, A, pl), x2, pl), pl);
+    r.Y = pconj(pmul(y2, pmul(pmul_const(D, c_phi<5>(), pl), Nn, pl), pl), pl);
+    r.Z = pconj(pmul(pmul(K, B, pl), Nn, pl), pl);
+    return r;
+}
+FQ_DEV PProj pchi(const PProj& p, const PairLane& pl) {                                      // curve4q.py:304-316
+    const PF<1> A = pconj(p.X, pl), B = pconj(p.Y, pl);
+    const PF<1> C = psqr(pconj(p.Z, pl), pl), D = psqr(A, pl);
+    const PF<1> G = pmul(B, padd(D, pmul_const(C, c_psi<2>(), pl)), pl);
+    const PF<2> H = pneg(padd(D, pmul_const(C, c_psi<4>(), pl)));
+    PProj r;
+    r.X = pmul(H, pmul(pmul_const(A, c_psi<1>(), pl), C, pl), pl);
+    r.Y = pmul(padd(D, pmul_const(C, c_psi<3>(), pl)), G, pl);
+    r.Z = pmul(H, G, pl);
+    return r;
+}
+
+// ---- the pair's table in LDS -----------------------------------------------------------------------------------------
+// 8 entries x 4 coordinates x 5 limbs per LANE (each lane keeps its half): 640 bytes per lane, 256 lanes = the CU's 160 KiB, so a
+// block is 128 elements and a generation 32 768.  Limb pairs (0,1), (2,3) live in a uint2 region and limb 4 in a u32 region, both
+// [value][lane]: consecutive lanes, consecutive banks, whatever the digits are.
+constexpr int PAIR_VALUES = 32;
+constexpr int PAIR_LDS_U32 = PAIR_VALUES * (2 * 2 + 1) * 256;                                // 163 840 bytes
+struct PairTable {
+    uint2* two;       // region of limb pairs + threadIdx.x
+    u32* one;         // region of limb 4 + threadIdx.x
+    template <int B> FQ_DEV void put(int v, const PF<B>& a) const {
+        two[(size_t)(2 * v) * 256] = make_uint2(a.l[0], a.l[1]);
+        two[(size_t)(2 * v + 1) * 256] = make_uint2(a.l[2], a.l[3]);
+        one[(size_t)v * 256] = a.l[4];
+    }
+    template <int B> FQ_DEV PF<B> get(u32 v) const {
+        const uint2 p = two[(size_t)(2 * v) * 256], q = two[(size_t)(2 * v + 1) * 256];
+        PF<B> r;
+        r.l[0] = p.x; r.l[1] = p.y; r.l[2] = q.x; r.l[3] = q.y; r.l[4] = one[(size_t)v * 256];
+        return r;
+    }
+    FQ_DEV void put_entry(int k, const PR2& t) const { put(4 * k, t.N); put(4 * k + 1, t.D); put(4 * k + 2, t.E); put(4 * k + 3, t.F); }
+    FQ_DEV PR2 get_entry(u32 k) const {
+        PR2 t;
+        t.N = get<2>(4 * k); t.D = get<2>(4 * k + 1); t.E = get<2>(4 * k + 2); t.F = get<1>(4 * k + 3);
+        return t;
+    }
+};
+
+// T[k] = P + k0*phi(P) + k1*psi(P) + k2*psi(phi(P)), built in the reference's order (curve4q.py:385-403): the structure of
+// build_table_endo (kernels.hip.h), with the three endomorphism evaluations sharing one instance of tau, chi / upsilon, tau_dual.
+// The working points stay in registers (a half point is 25 of them); the bases T[0..3] are read back from LDS.
+FQ_DEV void pair_build_table_endo(const PR1& P, const PairTable& tbl, const PairLane& pl) {
+    tbl.put_entry(0, pr1_to_r2(P, pl));
+    PF<1> X = P.X, Y = P.Y, Z = P.Z;               // step 0: P, step 1: tau(P) (shared by phi and psi), step 2: phi(P)
+    PF<1> QX = P.X, QY = P.Y, QZ = P.Z;            // phi(P), produced by step 0
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        PProj t;
+        if (step == 1) { t.X = X; t.Y = Y; t.Z = Z; }
+        else {
+            t = ptau(X, Y, Z, pl);
+            if (step == 0) { X = t.X; Y = t.Y; Z = t.Z; }        // keep tau(P) for step 1
+        }
+        const PProj u = step == 0 ? pupsilon(t, pl) : pchi(t, pl);
+        const PR1 V = ptau_dual(u.X, u.Y, u.Z, pl);
+        if (step == 0) { QX = V.X; QY = V.Y; QZ = V.Z; }
+        if (step == 1) { X = QX; Y = QY; Z = QZ; }               // step 2 works on phi(P)
+        const PR3 V3 = pr1_to_r3(V, pl);
+        const int half = 1 << step;
+#pragma unroll 1
+        for (int m = 0; m < half; m++) tbl.put_entry(half + m, pr1_to_r2(padd_core(V3, tbl.get_entry((u32)m), pl), pl));
+    }
+}
+
+// MUL_endo's ladder (curve4q.py:436-442) on the pair's table: the entry of a step is read from LDS a whole doubling ahead, its
+// sign applied by masked selects behind the doubling (as add_entry in curve.hip.h).
+FQ_DEV PR1 pair_ladder_endo(const EndoDigits& e, const PairTable& tbl, const PairLane& pl) {
+    const PR2 t0 = tbl.get_entry(e.top & 7);                  // s[64] = 1: the entry itself;  R2toR4: (N - D, D + N, E)
+    PR1 Q;
+    {   // the start point's coordinates are sums of bound-2 entries: one signed carry pass brings them to bound 1
+        const PF<4> x = psub(t0.N, t0.D), y = padd(t0.D, t0.N);
+        auto tighten = [](const auto& a) {
+            Fe<1> f = fe_unsign(reinterpret_cast<const Fe<4>&>(a));     // non-negative tight limbs of the same residue
+            PF<1> r;
+#pragma unroll
+            for (int i = 0; i < 5; i++) { r.l[i] = f.l[i]; FQ_SIGN_UNKNOWN(r.l[i]); }
+            return r;
+        };
+        Q.X = tighten(x); Q.Y = tighten(y);
+        const PF<4> z = pwiden<4>(t0.E);
+        Q.Z = tighten(z);
+    }
+#pragma unroll 1
+    for (int i = 63; i >= 0; i--) {
+        const u32 digit = endo_digit(e, i);
+        u32 neg = endo_neg_mask(e, i);
+        const PR2 t = tbl.get_entry(digit);
+        Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
+        asm("" : "+v"(neg) : "v"(Q.X.l[0]), "v"(Q.Y.l[0]), "v"(Q.Z.l[0]));      // the selects issue behind the doubling
+        PR2 s;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            s.N.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.D.l[k], t.N.l[k], 0xCA);
+            s.D.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.N.l[k], t.D.l[k], 0xCA);
+        }
+        s.E = t.E; s.F = pcneg(t.F, neg);
+        Q = padd_core(pr1_to_r3(Q, pl), s, pl);
+    }
+    return Q;
+}
+
+}  // namespace fq

@@ -183,6 +183,43 @@ def test_full_size_cfg5_mixed_vs_c_oracle(eng):
     assert 0.49 < flags.mean() < 0.51 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("pair_max", ["0", None])
+def test_one_lane_and_two_lane_kernels_on_small_batches_and_tails(pair_max, monkeypatch):
+    """Plain variable-base MUL_endo: batches of at most half a generation, and the tail of a batch past whole generations, run two
+    lanes per element (pair.hip.h: real parts in even lanes, imaginary parts in odd lanes); FOURQ_PAIR_MAX=0 keeps everything on
+    the one-lane fused kernel.  Same R1 tuples either way: edge scalars on G and -G, ragged sizes around the 128-element block,
+    the switch at half a generation, and a tail behind one fused generation -- every output against the C oracle."""
+    from fourq_amd import Engine
+    if pair_max is None:
+        monkeypatch.delenv("FOURQ_PAIR_MAX", raising=False)
+    else:
+        monkeypatch.setenv("FOURQ_PAIR_MAX", pair_max)
+    N = o.N
+    edge = [0, 1, 2, N - 1, N, N + 1, 2 * N, 1 << 255, (1 << 256) - 1]
+    negG = o.AffineToR1(o.GFp2.neg(o.Gx), o.Gy)
+    with Engine(0) as e:
+        lanes = e.lanes
+        s = codec.pack_scalars(edge + edge)
+        p = codec.pack_points([G1] * len(edge) + [negG] * len(edge), 5)
+        assert codec.unpack_points(e.mul_endo(s, p)) == [o.MUL_endo(m, P) for m, P in zip(edge + edge, [G1] * len(edge) + [negG] * len(edge))]
+        n = lanes + 300
+        sc = seeded_scalars(61, n)
+        pts = torsion_points(e, 62, n)
+        want = oc.mul(oc.ENDO, sc, pts)
+        for m in (1, 2, 127, 128, 129, 255, 4097, lanes // 2, lanes // 2 + 1, lanes + 1, lanes + 300):
+            assert np.array_equal(e.mul_endo(sc[:m], pts[:m]), want[:m]), (pair_max, m)
+        # device flavour, a 16-byte-aligned offset into bigger arrays (the pair kernel's halves are 16-byte accesses)
+        import torch
+        ds, dp = torch.from_numpy(sc.view(np.int64)).cuda(), torch.from_numpy(pts.view(np.int64)).cuda()
+        out = torch.zeros((n, 20), dtype=torch.int64, device="cuda")
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.mul_endo_dev(ds[3:], dp[3:], out[3:], 1000)
+        torch.cuda.synchronize()
+        e.set_stream(None)
+        got = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got[3:1003], want[3:1003]) and not got[:3].any() and not got[1003:].any()
+
+
 @pytest.mark.parametrize("queue", ["0", "1"])
 def test_mixed_batch_on_both_routes(queue, monkeypatch):
     """A mixed batch through round 2's three launches (FOURQ_MIXED_QUEUE=0) and through the persistent work-queue kernel

@@ -50,7 +50,9 @@ while time.time() < t_end:
         knobs["FOURQ_HOST_BOUNCE"] = "0"
     if rng.random() < 0.4:
         knobs["FOURQ_MIXED_QUEUE"] = rng.choice(["0", "1"])          # round 3: the persistent work-queue kernel forced on / off
-    for k in ("FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
+    if rng.random() < 0.3:
+        knobs["FOURQ_PAIR_MAX"] = rng.choice(["0", "100", "5000"])     # round 3: the two-lanes-per-element kernel off / for tiny tails only
+    for k in ("FOURQ_PAIR_MAX", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     with Engine(0) as eng:

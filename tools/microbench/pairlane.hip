@@ -176,6 +176,16 @@ int main() {
                best * 1e6 / (STEPS * REPS));
     }
     printf("pair-lane / shipped: B %.3f, B2 %.3f  (< 1 would be a gain)\n", times[1] / times[0], times[2] / times[0]);
+    {   // latency view: HALF the elements (one wave per SIMD of pair lanes): what a batch of <= 32 768 elements would pay per step
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); float ms = 0, best = 1e9;
+        for (int rep = 0; rep < 6; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(pair_kernel<false>, dim3(cus), dim3(256), 0, 0, d + 768, 12345u);
+            CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        printf("B at ONE wave per SIMD (32 768 elements): %8.3f ms -> %7.1f ns per step, %.3f of the shipped step's latency\n", best, best * 1e6 / (STEPS * REPS), best / times[0]);
+    }
     uint64_t h[3 * 768];
     CHECK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
     int same = 1;
