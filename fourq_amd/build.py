@@ -33,7 +33,7 @@ RESOURCE_POLICY = [
     (r"ladder_kernel<\d, 2,", "occupancy", lambda v: v >= 4, "the two-kernel route's ladders are sized for 4 waves per SIMD"),
     (r"ladder_kernel<\d, 1, false", "scratch", lambda v: v == 0, "the fixed-base MUL ladders must not spill"),
     (r"ladder_kernel<\d, 0,", "scratch", lambda v: v == 0, "the fused variable-base kernels must not spill to memory (AGPR copies are fine)"),
-    (r"pair_mul_endo_kernel", "scratch", lambda v: v == 0, "the two-lanes-per-element kernel must not spill"),
+    (r"pair_kernel<", "scratch", lambda v: v == 0, "the two-lanes-per-element kernel must not spill"),
     (r"prep_kernel<0, \w+>\(", "occupancy", lambda v: v >= 2, "prep_kernel<ENDO> hides its read-backs behind a second wave per SIMD"),
     (r"mixed_ct_tail_kernel<", "occupancy", lambda v: v >= 4, "the constant-time mixed-batch tail runs beside nothing only if it fits four waves per SIMD"),
     (r"comb_kernel<true, false>", "scratch", lambda v: v == 0, "the keygen comb of large batches (deferred normalisation) must not touch scratch memory"),

@@ -344,7 +344,7 @@ struct fourq_ctx {
     u32* part_fix = nullptr;       // constant-time mode: ids of the round's fixed-base elements
     bool ct = false;               // constant-time table selection (FOURQ_CT_SELECT / fourq_ctx_set_ct_select)
     int mixed_queue = -1;          // mixed batches through the persistent work-queue kernel: 1 always, 0 never, -1 = where it measured faster
-    size_t pair_max = 0;           // plain MUL_endo: batches (and tails past whole generations) of at most this many elements run two lanes per element
+    size_t pair_max = 0;           // variable-base batches (and tails past whole generations) of at most this many elements run two lanes per element
     uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
     size_t proj_capacity = 0;
     int norm_k = -1;               // FOURQ_NORM_K: 0 = always invert per element, 2/4/8 = always batch; -1 = by batch size
@@ -423,25 +423,26 @@ bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
     if (algo == WINDOWED || dh || c->split_all) return n >= c->split_min;
     return c->split_endo_min && n >= c->split_endo_min;
 }
-// Plain variable-base MUL_endo, two lanes per element (pair.hip.h): 0.58 of the one-lane kernel's latency for at most half a
-// generation of elements.  A batch that small runs on it alone; a batch of q generations + r elements, 0 < r <= pair_max, runs
-// q fused generations and then the r elements on it, so the element past a generation costs 0.6 of a generation instead of one.
-int launch_pair_endo(fourq_ctx* c, LadderArgs a) {
+// The variable-base kernels with two lanes per element (pair.hip.h): 0.66 of the one-lane kernels' latency for at most half a
+// generation of elements.  A batch that small runs on them alone; a batch of q generations + r elements, 0 < r <= pair_max, on the
+// fused route runs q fused generations and then the r elements two lanes each, so the element past a generation costs half a
+// generation instead of a whole one.  (The default selection mode only: the constant-time kernels keep their own layout.)
+template <int ALGO, bool DH> int launch_pair(fourq_ctx* c, LadderArgs a) {
     if (a.n == 0) return FOURQ_OK;
     const size_t blocks = ((size_t)a.n + BLOCK / 2 - 1) / (BLOCK / 2);
-    hipLaunchKernelGGL(pair_mul_endo_kernel<0>, dim3((unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus)), dim3(BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL((pair_kernel<ALGO, DH>), dim3((unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus)), dim3(BLOCK), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
 }
 template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
-    if (ALGO == ENDO && !DH && !c->ct && !a.index && c->pair_max && !takes_split_route(c, ALGO, DH, a.n)) {
+    if (!c->ct && !a.index && !a.proj && c->pair_max && !takes_split_route(c, ALGO, DH, a.n)) {
         const u32 tail = (u32)(a.n % c->lanes);
         if (tail != 0 && tail <= c->pair_max) {
             LadderArgs whole = a, rest = a;
             whole.n = a.n - tail;
             rest.base = a.base + whole.n; rest.n = tail;
             int rc = whole.n ? launch_ladder<ALGO, FUSED, DH>(c, whole) : FOURQ_OK;
-            return rc ? rc : launch_pair_endo(c, rest);
+            return rc ? rc : launch_pair<ALGO, DH>(c, rest);
         }
     }
     if (!takes_split_route(c, ALGO, DH, a.n)) return launch_ladder<ALGO, FUSED, DH>(c, a);

@@ -574,11 +574,11 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
     }
 }
 
-// ---- two lanes per element (pair.hip.h): variable-base MUL_endo for small batches and for the tail past whole generations ------
+// ---- two lanes per element (pair.hip.h): the variable-base kernels for small batches and for the tail past whole generations --
 // 128 elements per 256-lane block (the pair's table fills the CU's LDS), one block per CU, grid-stride over the batch.  Each lane
-// loads, computes and stores ITS half (real or imaginary parts) of every coordinate; the scalar is decomposed in both lanes.
-template <int UNIT_ONLY = 0>
-__global__ __launch_bounds__(BLOCK, 1) void pair_mul_endo_kernel(LadderArgs a) {
+// loads, computes and stores ITS half (real or imaginary parts) of every coordinate; the scalar is recoded in both lanes.
+template <int ALGO, bool DH>
+__global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
     __shared__ __attribute__((aligned(16))) u32 lds_pair[PAIR_LDS_U32];
     PairTable tbl;
     tbl.two = reinterpret_cast<uint2*>(lds_pair) + threadIdx.x;
@@ -586,6 +586,7 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_mul_endo_kernel(LadderArgs a) {
     const u32 odd = threadIdx.x & 1;
     const PairLane pl{ odd - 1u, 0u - odd };
     constexpr u32 PER_BLOCK = BLOCK / 2;
+    constexpr int IN_WORDS = DH ? 8 : 20, OUT_WORDS = DH ? 8 : 20;
     const u32 n = a.n, n_round = (n + PER_BLOCK - 1) / PER_BLOCK * PER_BLOCK;
 #pragma unroll 1
     for (u32 it = blockIdx.x * PER_BLOCK + (threadIdx.x >> 1); it < n_round; it += gridDim.x * PER_BLOCK) {
@@ -593,31 +594,56 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_mul_endo_kernel(LadderArgs a) {
         const u32 id = a.base + (live ? it : n - 1);             // idle tail pairs redo the last element, store nothing
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
-        auto half = [&](int c) {                                  // this lane's half of coordinate c of the R1 point: words 4c + 2 odd, + 1
-            const uint4 w = *reinterpret_cast<const uint4*>(a.points + 20 * (size_t)id + 4 * c + 2 * odd);
+        auto half = [&](int c) {                                  // this lane's half of coordinate c of the input point: words 4c + 2 odd, + 1
+            const uint4 w = *reinterpret_cast<const uint4*>(a.points + IN_WORDS * (size_t)id + 4 * c + 2 * odd);
             const Fe<1> f = fe_unpack((u64)w.x | ((u64)w.y << 32), (u64)w.z | ((u64)w.w << 32));
             PF<1> r;
 #pragma unroll
             for (int i = 0; i < 5; i++) { r.l[i] = f.l[i]; FQ_SIGN_UNKNOWN(r.l[i]); }
             return r;
         };
+        auto store_half = [&](int c, u64 lo, u64 hi) {
+            *reinterpret_cast<uint4*>(a.out + OUT_WORDS * (size_t)id + 4 * c + 2 * odd) = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+        };
+        uint8_t st = FOURQ_DH_OK;
         PR1 P;
-        P.X = half(0); P.Y = half(1); P.Z = half(2); P.Ta = pwiden<3>(half(3)); P.Tb = pwiden<2>(half(4));
-        pair_build_table_endo(P, tbl, pl);
-        u64 v[4];
-        decompose(m, v);
-        const PR1 Q = pair_ladder_endo(recode(v), tbl, pl);
-        if (live) {
-            auto store_half = [&](int c, const Fe<1>& f) {
-                u64 lo, hi;
-                fe_canon(f, lo, hi);
-                *reinterpret_cast<uint4*>(a.out + 20 * (size_t)id + 4 * c + 2 * odd) = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-            };
-            store_half(0, fe_unsign(reinterpret_cast<const Fe<1>&>(Q.X)));
-            store_half(1, fe_unsign(reinterpret_cast<const Fe<1>&>(Q.Y)));
-            store_half(2, fe_unsign(reinterpret_cast<const Fe<1>&>(Q.Z)));
-            store_half(3, fe_unsign(reinterpret_cast<const Fe<3>&>(Q.Ta)));
-            store_half(4, fe_unsign(reinterpret_cast<const Fe<2>&>(Q.Tb)));
+        if constexpr (DH) {
+            const PF<1> x = half(0), y = half(1);
+            if (!pair_point_on_curve(x, y, pl)) st = FOURQ_DH_NOT_ON_CURVE;      // keep going branch-free; masked at the end
+            P = pair_clear_cofactor_392(x, y, pl);
+        } else {
+            P.X = half(0); P.Y = half(1); P.Z = half(2); P.Ta = pwiden<3>(half(3)); P.Tb = pwiden<2>(half(4));
+        }
+        PR1 Q;
+        if constexpr (ALGO == ENDO) {
+            pair_build_table_endo(P, tbl, pl);
+            u64 v[4];
+            decompose(m, v);
+            Q = pair_ladder_endo(recode(v), tbl, pl);
+        } else {
+            pair_build_table_windowed(P, tbl, pl);
+            Q = pair_ladder_windowed(win_reduce(m), tbl, pl);
+        }
+        if constexpr (DH) {
+            PF<1> ax, ay;
+            pair_to_affine(Q, pl, ax, ay);
+            u64 x0, x1, y0, y1;
+            pair_canon(ax, x0, x1); pair_canon(ay, y0, y1);
+            // (Ox, Oy) = ((0, 0), (1, 0)): this lane's half of it is (0, 1) on even lanes and (0, 0) on odd ones
+            const u32 neutral = pair_both(((x0 | x1 | y1) == 0 && y0 == (u64)(pl.even & 1u)) ? 1u : 0u);
+            if (st == FOURQ_DH_OK && neutral) st = FOURQ_DH_NEUTRAL;
+            if (live) {
+                store_half(0, st ? 0 : x0, st ? 0 : x1);
+                store_half(1, st ? 0 : y0, st ? 0 : y1);
+                if (!odd) a.status[id] = st;
+            }
+        } else if (live) {
+            u64 lo, hi;
+            pair_canon(Q.X, lo, hi); store_half(0, lo, hi);
+            pair_canon(Q.Y, lo, hi); store_half(1, lo, hi);
+            pair_canon(Q.Z, lo, hi); store_half(2, lo, hi);
+            pair_canon(Q.Ta, lo, hi); store_half(3, lo, hi);
+            pair_canon(Q.Tb, lo, hi); store_half(4, lo, hi);
         }
     }
 }

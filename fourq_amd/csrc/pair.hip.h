@@ -295,39 +295,117 @@ FQ_DEV void pair_build_table_endo(const PR1& P, const PairTable& tbl, const Pair
 
 // MUL_endo's ladder (curve4q.py:436-442) on the pair's table: the entry of a step is read from LDS a whole doubling ahead, its
 // sign applied by masked selects behind the doubling (as add_entry in curve.hip.h).
+FQ_DEV PR1 pair_start(const PR2& t, u32 neg);
+FQ_DEV PR1 padd_signed_entry(const PR1& Q, const PR2& t, u32 neg, const PairLane& pl);
 FQ_DEV PR1 pair_ladder_endo(const EndoDigits& e, const PairTable& tbl, const PairLane& pl) {
-    const PR2 t0 = tbl.get_entry(e.top & 7);                  // s[64] = 1: the entry itself;  R2toR4: (N - D, D + N, E)
-    PR1 Q;
-    {   // the start point's coordinates are sums of bound-2 entries: one signed carry pass brings them to bound 1
-        const PF<4> x = psub(t0.N, t0.D), y = padd(t0.D, t0.N);
-        auto tighten = [](const auto& a) {
-            Fe<1> f = fe_unsign(reinterpret_cast<const Fe<4>&>(a));     // non-negative tight limbs of the same residue
-            PF<1> r;
-#pragma unroll
-            for (int i = 0; i < 5; i++) { r.l[i] = f.l[i]; FQ_SIGN_UNKNOWN(r.l[i]); }
-            return r;
-        };
-        Q.X = tighten(x); Q.Y = tighten(y);
-        const PF<4> z = pwiden<4>(t0.E);
-        Q.Z = tighten(z);
-    }
+    PR1 Q = pair_start(tbl.get_entry(e.top & 7), 0u);         // s[64] = 1: the entry itself
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
-        const u32 digit = endo_digit(e, i);
-        u32 neg = endo_neg_mask(e, i);
-        const PR2 t = tbl.get_entry(digit);
+        const PR2 t = tbl.get_entry(endo_digit(e, i));        // read a whole doubling ahead of its use
         Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
-        asm("" : "+v"(neg) : "v"(Q.X.l[0]), "v"(Q.Y.l[0]), "v"(Q.Z.l[0]));      // the selects issue behind the doubling
-        PR2 s;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            s.N.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.D.l[k], t.N.l[k], 0xCA);
-            s.D.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.N.l[k], t.D.l[k], 0xCA);
-        }
-        s.E = t.E; s.F = pcneg(t.F, neg);
-        Q = padd_core(pr1_to_r3(Q, pl), s, pl);
+        Q = padd_signed_entry(Q, t, endo_neg_mask(e, i), pl);
     }
     return Q;
+}
+
+// T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                                      curve4q.py:179-185
+FQ_DEV void pair_build_table_windowed(const PR1& P, const PairTable& tbl, const PairLane& pl) {
+    const PR3 twoP = pr1_to_r3(pdbl_point(P.X, P.Y, P.Z, pl), pl);
+    PR2 t = pr1_to_r2(P, pl);
+    tbl.put_entry(0, t);
+#pragma unroll 1
+    for (int i = 1; i < 8; i++) {
+        t = pr1_to_r2(padd_core(twoP, t, pl), pl);
+        tbl.put_entry(i, t);
+    }
+}
+// a sum of table coordinates (bound <= 4) as a bound-1 half with non-negative tight limbs of the same residue
+template <int B> FQ_DEV PF<1> ptighten(const PF<B>& a) {
+    const Fe<1> f = fe_unsign(reinterpret_cast<const Fe<B>&>(a));
+    PF<1> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { r.l[i] = f.l[i]; FQ_SIGN_UNKNOWN(r.l[i]); }
+    return r;
+}
+// Q + (+-T): the entry's sign by masked selects behind whatever produced Q (as add_entry in curve.hip.h)
+FQ_DEV PR1 padd_signed_entry(const PR1& Q, const PR2& t, u32 neg, const PairLane& pl) {
+    asm("" : "+v"(neg) : "v"(Q.X.l[0]), "v"(Q.Y.l[0]), "v"(Q.Z.l[0]));
+    PR2 s;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        s.N.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.D.l[k], t.N.l[k], 0xCA);
+        s.D.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.N.l[k], t.D.l[k], 0xCA);
+    }
+    s.E = t.E; s.F = pcneg(t.F, neg);
+    return padd_core(pr1_to_r3(Q, pl), s, pl);
+}
+// R2toR4(selectpt(s, T, R2neg(T))): the ladders' starting point (curve4q.py:229, :437)
+FQ_DEV PR1 pair_start(const PR2& t, u32 neg) {
+    PF<2> N, D;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        N.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.D.l[k], t.N.l[k], 0xCA);
+        D.l[k] = __builtin_amdgcn_bitop3_b32(neg, t.N.l[k], t.D.l[k], 0xCA);
+    }
+    PR1 Q;
+    Q.X = ptighten(psub(N, D)); Q.Y = ptighten(padd(D, N)); Q.Z = ptighten(t.E);
+    Q.Ta = pwiden<3>(Q.X); Q.Tb = pwiden<2>(Q.Y);
+    return Q;
+}
+FQ_DEV PR1 pair_ladder_windowed(const WinScalar& w, const PairTable& tbl, const PairLane& pl) {     // curve4q.py:228-235
+    u32 code = win_top_code(w);
+    PR1 Q = pair_start(tbl.get_entry(code & 7), (code >> 3) - 1u);
+#pragma unroll 1
+    for (int i = 61; i >= 0; i--) {
+        code = win_code_from_window(win_window(w, i));
+        const PR2 t = tbl.get_entry(code & 7);
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
+        Q = padd_signed_entry(Q, t, (code >> 3) - 1u, pl);
+    }
+    return Q;
+}
+
+// ---- the DH wrapper (curve4q.py:446-462) ---------------------------------------------------------------------------------
+FQ_DEV PF<1> pair_one(const PairLane& pl) { PF<1> r; r.l[0] = pl.even & 1u; r.l[1] = r.l[2] = r.l[3] = r.l[4] = 0; return r; }   // (1, 0)
+template <int B> FQ_DEV void pair_canon(const PF<B>& a, u64& lo, u64& hi) { fe_canon(fe_unsign(reinterpret_cast<const Fe<B>&>(a)), lo, hi); }
+FQ_DEV u32 pair_both(u32 flag) { return flag & (u32)__builtin_amdgcn_mov_dpp((int)flag, DPP_SWAP, 0xF, 0xF, true); }    // true in both halves
+FQ_DEV u32 pair_point_on_curve(const PF<1>& x, const PF<1>& y, const PairLane& pl) {                // curve4q.py:23-29
+    const PF<1> x2 = psqr(x, pl), y2 = psqr(y, pl);
+    const PF<2> lhs = psub(y2, x2);
+    const PF<2> rhs = padd(pair_one(pl), pmul(y2, pmul_const(x2, c_d(), pl), pl));
+    u64 a0, a1, b0, b1;
+    pair_canon(lhs, a0, a1); pair_canon(rhs, b0, b1);
+    return pair_both((a0 == b0 && a1 == b1) ? 1u : 0u);
+}
+FQ_DEV PR1 pair_clear_cofactor_392(const PF<1>& x, const PF<1>& y, const PairLane& pl) {            // curve4q.py:450-455
+    PR1 p0;
+    p0.X = x; p0.Y = y; p0.Z = pair_one(pl); p0.Ta = pwiden<3>(x); p0.Tb = pwiden<2>(y);
+    const PR2 t0 = pr1_to_r2(p0, pl);
+    PR1 q = padd_core(pr1_to_r3(pdbl_point(p0.X, p0.Y, p0.Z, pl), pl), t0, pl);       // 3P
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) q = pdbl_point(q.X, q.Y, q.Z, pl);                    // 48P
+    q = padd_core(pr1_to_r3(q, pl), t0, pl);                                          // 49P
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) q = pdbl_point(q.X, q.Y, q.Z, pl);                    // 392P
+    return q;
+}
+// R1toAffine (curve4q.py:103-106, fields.py:193-199): 1/Z = conj(Z) / (Z_re^2 + Z_im^2).  Each lane squares its half of Z, the norm
+// is completed by one exchange, BOTH lanes run the GF(p) inversion chain on it (the same instructions: no cost beyond one lane's).
+FQ_DEV void pair_to_affine(const PR1& Q, const PairLane& pl, PF<1>& ax, PF<1>& ay) {
+    const Fe<1> zh = fe_unsign(reinterpret_cast<const Fe<1>&>(Q.Z));
+    const Fe<1> sq = fe_sqr(zh);
+    Fe<1> other;
+#pragma unroll
+    for (int i = 0; i < 5; i++) other.l[i] = (u32)__builtin_amdgcn_mov_dpp((int)sq.l[i], DPP_SWAP, 0xF, 0xF, true);
+    const Fe<1> ninv = fe_inv(fe_carry(fe_add(sq, other)));
+    const Fe<1> zi_abs = fe_mul(ninv, zh);                                  // |half| of conj(Z) / norm
+    const Fe<1> zi_neg = fe_carry(fe_neg(zi_abs));
+    PF<1> zi;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { zi.l[i] = __builtin_amdgcn_bitop3_b32(pl.odd_neg, zi_neg.l[i], zi_abs.l[i], 0xCA); FQ_SIGN_UNKNOWN(zi.l[i]); }
+    ax = pmul(Q.X, zi, pl);
+    ay = pmul(Q.Y, zi, pl);
 }
 
 }  // namespace fq

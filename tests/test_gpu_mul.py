@@ -218,6 +218,29 @@ def test_one_lane_and_two_lane_kernels_on_small_batches_and_tails(pair_max, monk
         e.set_stream(None)
         got = out.cpu().numpy().view(np.uint64)
         assert np.array_equal(got[3:1003], want[3:1003]) and not got[:3].any() and not got[1003:].any()
+        # the other variable-base entry points take the same route: MUL_windowed, DH_endo / DH_windowed with both rejections
+        k = 5000
+        want_w = oc.mul(oc.WINDOWED, sc[:k], pts[:k])
+        for m in (1, 129, k):
+            assert np.array_equal(e.mul_windowed(sc[:m], pts[:m]), want_w[:m]), (pair_max, m)
+        aff = e.prim("PT_R1TOAFFINE", pts[:k]).copy()
+        aff[7, 0] ^= 1                                            # not on the curve
+        P392 = codec.pack_point(_kat_p392())
+        aff[11] = P392                                            # order divides 392: the neutral point after cofactor clearing
+        for algo, fn in ((oc.ENDO, e.dh_endo), (oc.WINDOWED, e.dh_windowed)):
+            want_d, want_st = oc.dh(algo, sc[:k], aff)
+            for m in (1, 12, 129, k):
+                got_d, got_st = fn(sc[:m], aff[:m])
+                assert np.array_equal(got_st, want_st[:m]) and np.array_equal(got_d, want_d[:m]), (pair_max, algo, m)
+            assert want_st[7] == 1 and want_st[11] == 2
+
+
+def _kat_p392():
+    import json
+    import os
+    from conftest import GOLDEN, unhex
+    with open(os.path.join(GOLDEN, "kat.json")) as fh:
+        return unhex(json.load(fh)["P392"])
 
 
 @pytest.mark.parametrize("queue", ["0", "1"])
