@@ -434,18 +434,29 @@ template <int ALGO, bool DH> int launch_pair(fourq_ctx* c, LadderArgs a) {
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
 }
+// The route of a variable-base batch.  PAIR_TAIL: whole fused generations, then the remainder two lanes per element (also a batch
+// that is nothing but such a remainder).  Below two generations it beats the two-kernel route for every entry point (65 792
+// elements: DH_endo 0.69 against 0.74 ms, MUL_windowed 1.10 against 1.19); from two generations on the two-kernel route's four
+// wave slots per SIMD absorb a remainder by themselves.
+enum Route { ROUTE_FUSED, ROUTE_PAIR_TAIL, ROUTE_SPLIT };
+Route variable_route(const fourq_ctx* c, int algo, bool dh, size_t n, bool indexed) {
+    const size_t tail = n % c->lanes;
+    const bool pair_tail = !c->ct && !indexed && c->pair_max && tail != 0 && tail <= c->pair_max;
+    if (pair_tail && n < 2 * c->lanes) return ROUTE_PAIR_TAIL;
+    if (takes_split_route(c, algo, dh, n)) return ROUTE_SPLIT;
+    return pair_tail ? ROUTE_PAIR_TAIL : ROUTE_FUSED;
+}
 template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
-    if (!c->ct && !a.index && !a.proj && c->pair_max && !takes_split_route(c, ALGO, DH, a.n)) {
+    const Route route = variable_route(c, ALGO, DH, a.n, a.index != nullptr);
+    if (route == ROUTE_PAIR_TAIL) {
         const u32 tail = (u32)(a.n % c->lanes);
-        if (tail != 0 && tail <= c->pair_max) {
-            LadderArgs whole = a, rest = a;
-            whole.n = a.n - tail;
-            rest.base = a.base + whole.n; rest.n = tail;
-            int rc = whole.n ? launch_ladder<ALGO, FUSED, DH>(c, whole) : FOURQ_OK;
-            return rc ? rc : launch_pair<ALGO, DH>(c, rest);
-        }
+        LadderArgs whole = a, rest = a;
+        whole.n = a.n - tail;
+        rest.base = a.base + whole.n; rest.n = tail;
+        int rc = whole.n ? launch_ladder<ALGO, FUSED, DH>(c, whole) : FOURQ_OK;
+        return rc ? rc : launch_pair<ALGO, DH>(c, rest);
     }
-    if (!takes_split_route(c, ALGO, DH, a.n)) return launch_ladder<ALGO, FUSED, DH>(c, a);
+    if (route == ROUTE_FUSED) return launch_ladder<ALGO, FUSED, DH>(c, a);
     const u32 total = a.n;
     for (u32 off = 0; off < total; off += (u32)c->split_chunk) {
         LadderArgs part = a;
@@ -528,7 +539,7 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
     a.scalars = scalars; a.points = points; a.out = out; a.status = status; a.n = (u32)n;
     int group = normalize_group(c, n);
     if (!table) {                                  // fused kernels invert in place; the prep + ladder route always defers
-        const bool split = takes_split_route(c, algo, true, n);
+        const bool split = variable_route(c, algo, true, n, false) == ROUTE_SPLIT;
         group = split ? (group ? group : 1) : 0;
     }
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
