@@ -426,11 +426,16 @@ bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
 // The variable-base kernels with two lanes per element (pair.hip.h): 0.66 of the one-lane kernels' latency for at most half a
 // generation of elements.  A batch that small runs on them alone; a batch of q generations + r elements, 0 < r <= pair_max, on the
 // fused route runs q fused generations and then the r elements two lanes each, so the element past a generation costs half a
-// generation instead of a whole one.  (The default selection mode only: the constant-time kernels keep their own layout.)
+// generation instead of a whole one.  Both selection modes.
 template <int ALGO, bool DH> int launch_pair(fourq_ctx* c, LadderArgs a) {
     if (a.n == 0) return FOURQ_OK;
     const size_t blocks = ((size_t)a.n + BLOCK / 2 - 1) / (BLOCK / 2);
-    hipLaunchKernelGGL((pair_kernel<ALGO, DH>), dim3((unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus)), dim3(BLOCK), 0, c->stream, a);
+    const unsigned grid = (unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus);
+    if (c->ct) {                            // fourq_ct_fused.hip: the same kernels with the lane's table scanned at every step
+        HIPRC_TRY(c, ct_launch_pair(ALGO, DH, grid, c->stream, a));
+        return FOURQ_OK;
+    }
+    hipLaunchKernelGGL((pair_kernel<ALGO, DH>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
 }
@@ -441,7 +446,7 @@ template <int ALGO, bool DH> int launch_pair(fourq_ctx* c, LadderArgs a) {
 enum Route { ROUTE_FUSED, ROUTE_PAIR_TAIL, ROUTE_SPLIT };
 Route variable_route(const fourq_ctx* c, int algo, bool dh, size_t n, bool indexed) {
     const size_t tail = n % c->lanes;
-    const bool pair_tail = !c->ct && !indexed && c->pair_max && tail != 0 && tail <= c->pair_max;
+    const bool pair_tail = !indexed && c->pair_max && tail != 0 && tail <= c->pair_max;
     if (pair_tail && n < 2 * c->lanes) return ROUTE_PAIR_TAIL;
     if (takes_split_route(c, algo, dh, n)) return ROUTE_SPLIT;
     return pair_tail ? ROUTE_PAIR_TAIL : ROUTE_FUSED;

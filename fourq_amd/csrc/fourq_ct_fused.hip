@@ -19,6 +19,16 @@ int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const 
     return (int)hipGetLastError();
 }
 
+int ct_launch_pair(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    if (algo == ENDO) {
+        if (dh) hipLaunchKernelGGL((pair_kernel<ENDO, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((pair_kernel<ENDO, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    } else {
+        if (dh) hipLaunchKernelGGL((pair_kernel<WINDOWED, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((pair_kernel<WINDOWED, false, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    }
+    return (int)hipGetLastError();
+}
 int ct_launch_mixed_queue(unsigned grid, hipStream_t stream, const LadderArgs& a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head) {
     hipLaunchKernelGGL(mixed_queue_kernel<true>, dim3(grid), dim3(BLOCK), 0, stream, a, var_list, fix_list, counts, queue_head);
     return (int)hipGetLastError();

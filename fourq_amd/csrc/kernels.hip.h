@@ -577,7 +577,8 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 // ---- two lanes per element (pair.hip.h): the variable-base kernels for small batches and for the tail past whole generations --
 // 128 elements per 256-lane block (the pair's table fills the CU's LDS), one block per CU, grid-stride over the batch.  Each lane
 // loads, computes and stores ITS half (real or imaginary parts) of every coordinate; the scalar is recoded in both lanes.
-template <int ALGO, bool DH>
+// CT: constant-time table selection -- the lane scans its eight entries in LDS at every step (PairTable::scan_entry).
+template <int ALGO, bool DH, bool CT = false>
 __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
     __shared__ __attribute__((aligned(16))) u32 lds_pair[PAIR_LDS_U32];
     PairTable tbl;
@@ -619,10 +620,10 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
             pair_build_table_endo(P, tbl, pl);
             u64 v[4];
             decompose(m, v);
-            Q = pair_ladder_endo(recode(v), tbl, pl);
+            Q = pair_ladder_endo<CT>(recode(v), tbl, pl);
         } else {
             pair_build_table_windowed(P, tbl, pl);
-            Q = pair_ladder_windowed(win_reduce(m), tbl, pl);
+            Q = pair_ladder_windowed<CT>(win_reduce(m), tbl, pl);
         }
         if constexpr (DH) {
             PF<1> ax, ay;
@@ -916,6 +917,7 @@ int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, con
 int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
 // constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_pair(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
                          u32* over_scratch, u32 lanes, u32 limit);     // split_counts_kernel must already have run: see fourq_ct_chain.hip
 int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit);

@@ -265,6 +265,26 @@ struct PairTable {
         t.N = get<2>(4 * k); t.D = get<2>(4 * k + 1); t.E = get<2>(4 * k + 2); t.F = get<1>(4 * k + 3);
         return t;
     }
+    // constant-time selection (curve.hip.h, "constant-time selection"): EVERY entry is read -- the lane's LDS addresses depend on the
+    // lane and the entry number, never on the digit -- and the wanted one kept by masks derived arithmetically from the digit
+    FQ_DEV PR2 scan_entry(u32 digit) const {
+        u32 acc[20];
+#pragma unroll
+        for (int i = 0; i < 20; i++) acc[i] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const PR2 t = get_entry((u32)k);
+            const u32 m = eq_mask(digit, (u32)k);
+#pragma unroll
+            for (int i = 0; i < 5; i++) { acc[i] |= t.N.l[i] & m; acc[5 + i] |= t.D.l[i] & m; acc[10 + i] |= t.E.l[i] & m; acc[15 + i] |= t.F.l[i] & m; }
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);      // two entries per round: left alone the scheduler hoists all 96 reads ahead of the masking
+        }
+        PR2 r;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { r.N.l[i] = acc[i]; r.D.l[i] = acc[5 + i]; r.E.l[i] = acc[10 + i]; r.F.l[i] = acc[15 + i]; }
+        return r;
+    }
+    template <bool CT> FQ_DEV PR2 select_entry(u32 digit) const { if constexpr (CT) return scan_entry(digit); else return get_entry(digit); }
 };
 
 // T[k] = P + k0*phi(P) + k1*psi(P) + k2*psi(phi(P)), built in the reference's order (curve4q.py:385-403): the structure of
@@ -297,11 +317,11 @@ FQ_DEV void pair_build_table_endo(const PR1& P, const PairTable& tbl, const Pair
 // sign applied by masked selects behind the doubling (as add_entry in curve.hip.h).
 FQ_DEV PR1 pair_start(const PR2& t, u32 neg);
 FQ_DEV PR1 padd_signed_entry(const PR1& Q, const PR2& t, u32 neg, const PairLane& pl);
-FQ_DEV PR1 pair_ladder_endo(const EndoDigits& e, const PairTable& tbl, const PairLane& pl) {
-    PR1 Q = pair_start(tbl.get_entry(e.top & 7), 0u);         // s[64] = 1: the entry itself
+template <bool CT> FQ_DEV PR1 pair_ladder_endo(const EndoDigits& e, const PairTable& tbl, const PairLane& pl) {
+    PR1 Q = pair_start(tbl.select_entry<CT>(e.top & 7), 0u);  // s[64] = 1: the entry itself
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
-        const PR2 t = tbl.get_entry(endo_digit(e, i));        // read a whole doubling ahead of its use
+        const PR2 t = tbl.select_entry<CT>(endo_digit(e, i)); // read a whole doubling ahead of its use
         Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
         Q = padd_signed_entry(Q, t, endo_neg_mask(e, i), pl);
     }
@@ -352,13 +372,13 @@ FQ_DEV PR1 pair_start(const PR2& t, u32 neg) {
     Q.Ta = pwiden<3>(Q.X); Q.Tb = pwiden<2>(Q.Y);
     return Q;
 }
-FQ_DEV PR1 pair_ladder_windowed(const WinScalar& w, const PairTable& tbl, const PairLane& pl) {     // curve4q.py:228-235
+template <bool CT> FQ_DEV PR1 pair_ladder_windowed(const WinScalar& w, const PairTable& tbl, const PairLane& pl) {     // curve4q.py:228-235
     u32 code = win_top_code(w);
-    PR1 Q = pair_start(tbl.get_entry(code & 7), (code >> 3) - 1u);
+    PR1 Q = pair_start(tbl.select_entry<CT>(code & 7), (code >> 3) - 1u);
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
         code = win_code_from_window(win_window(w, i));
-        const PR2 t = tbl.get_entry(code & 7);
+        const PR2 t = tbl.select_entry<CT>(code & 7);
 #pragma unroll 1
         for (int k = 0; k < 4; k++) Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
         Q = padd_signed_entry(Q, t, (code >> 3) - 1u, pl);

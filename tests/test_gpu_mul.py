@@ -208,6 +208,11 @@ def test_one_lane_and_two_lane_kernels_on_small_batches_and_tails(pair_max, monk
         want = oc.mul(oc.ENDO, sc, pts)
         for m in (1, 2, 127, 128, 129, 255, 4097, lanes // 2, lanes // 2 + 1, lanes + 1, lanes + 300):
             assert np.array_equal(e.mul_endo(sc[:m], pts[:m]), want[:m]), (pair_max, m)
+        e.ct_select = True                                        # the pair-lane kernels with the lane's table scanned at every step
+        for m in (1, 129, 4097, lanes + 300):
+            assert np.array_equal(e.mul_endo(sc[:m], pts[:m]), want[:m]), (pair_max, "ct", m)
+        assert codec.unpack_points(e.mul_endo(s, p)) == [o.MUL_endo(m, P) for m, P in zip(edge + edge, [G1] * len(edge) + [negG] * len(edge))]
+        e.ct_select = False
         # device flavour, a 16-byte-aligned offset into bigger arrays (the pair kernel's halves are 16-byte accesses)
         import torch
         ds, dp = torch.from_numpy(sc.view(np.int64)).cuda(), torch.from_numpy(pts.view(np.int64)).cuda()

@@ -82,7 +82,7 @@ def operands(ins):
 ADDRESS_OPS = ("v_add_u32", "v_add_co_u32", "v_addc_co_u32", "v_add_nc_u32", "v_add3_u32", "v_lshl_add_u32", "v_lshl_add_u64", "v_add_lshl_u32",
                "v_mov_b32", "v_mov_b64", "v_or_b32", "v_lshlrev_b32", "v_lshlrev_b64", "v_accvgpr_read", "v_accvgpr_write", "v_mad_u32_u24", "v_mul_u32_u24",
                "v_and_b32", "v_or3_b32", "v_lshl_or_b32", "v_and_or_b32")
-LADDER_MADS = (1300, 1200)           # static multiply-adds of one ladder step (DBL + ADD; 4 DBL in an inner loop + ADD) / one comb column
+LADDER_MADS = (1300, 1200, 650)      # static multiply-adds of one ladder step (DBL + ADD; 4 DBL in an inner loop + ADD) / one comb column / a pair-lane step
 
 
 def defs_of(ins):
@@ -227,7 +227,7 @@ def audit_units(units, tmp=None):
         if p.wait() != 0:
             raise SystemExit("hipcc failed on %s" % u)
         for name, body in kernels(open(out).read().splitlines()):
-            if not any(k in name for k in ("ladder_kernel", "comb_kernel", "mixed_queue_kernel", "mixed_ct_tail_kernel")):
+            if not any(k in name for k in ("ladder_kernel", "comb_kernel", "mixed_queue_kernel", "mixed_ct_tail_kernel", "pair_kernel")):
                 continue
             checked, bad = audit_kernel(name, body)
             rows.append((u, name, checked, len(bad)))
