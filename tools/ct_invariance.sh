@@ -9,7 +9,7 @@ CLASSES=${CT_CLASSES:-"random zero ones same"}          # CT_CLASSES / CT_TRACE_
 ROOTDIR=$(pwd); export TMPDIR=/tmp
 OUT=$ROOTDIR/gpurun_out/ct_inv; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-for mode in ct default; do
+for mode in ${CT_MODES:-ct default}; do
   for cls in $CLASSES; do
     ARGS="$ROOTDIR/tools/ct_probe.py --mode $mode --scalars $cls --n $N"
     rocprofv3 --kernel-trace --output-format csv -d $OUT/${mode}_${cls}_trace -- python3 $ARGS > $OUT/${mode}_${cls}_trace.log 2>&1 || { tail -5 $OUT/${mode}_${cls}_trace.log; exit 1; }

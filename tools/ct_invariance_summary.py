@@ -10,7 +10,7 @@ import sys
 
 root = sys.argv[1]
 CLASSES = ["random", "zero", "ones", "same"]
-SUBJECT = ("ladder_kernel", "comb_kernel", "normalize_kernel", "prep_kernel")
+SUBJECT = ("ladder_kernel", "comb_kernel", "normalize_kernel", "prep_kernel", "pair_kernel")
 
 
 def short(name):
@@ -32,6 +32,8 @@ def tail_launches(rs, key, per_kernel):
 
 
 for mode in ("ct", "default"):
+    if not glob.glob(os.path.join(root, mode + "_*_trace")):
+        continue
     print("## selection mode: %s" % ("constant-time (fourq_ctx_set_ct_select = 1)" if mode == "ct" else "default (digit = table address, as the reference)"))
     table = collections.defaultdict(dict)          # (kernel, counter) -> {class: mean}
     for cls in CLASSES:
