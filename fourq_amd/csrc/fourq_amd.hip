@@ -4,7 +4,9 @@
 //
 // Kernel design (gfx950): one wavefront lane owns one (scalar, point) pair for the whole scalar
 // multiplication.  Lanes never communicate; a workgroup is 256 lanes; the grid is sized to the
-// number of resident lanes and strides over the batch.
+// number of resident lanes and strides over the batch.  (The exception: variable-base batches of at most
+// half a generation, and remainders past whole generations, run TWO lanes per element -- real parts in even
+// lanes, imaginary parts in odd lanes, halves exchanged by DPP -- at 0.66 of the latency: pair.hip.h.)
 //
 //   variable base : the lane builds its own 8-entry R2 table (table_endo / table_windowed): N, D of every entry into
 //                   a 768-byte slot of HBM scratch (96 bytes per entry = two memory sectors), E, F into its rows of

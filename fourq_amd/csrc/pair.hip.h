@@ -1,17 +1,19 @@
-// Two lanes per element: variable-base MUL_endo for SMALL batches and for the tail of a batch past whole generations.
+// Two lanes per element: the variable-base kernels (MUL_endo, MUL_windowed, DH_*; both selection modes) for SMALL batches and for
+// the remainder of a batch past whole generations.
 //
 // One lane owns one scalar multiplication for 0.33 ms of dependent instructions however few lanes are busy (DESIGN.md section 9:
 // the generation cliff), so a batch of 100 elements and the 256 elements past a full generation each cost what 65 536 cost.
 // Here lane 2k holds the REAL parts and lane 2k + 1 the IMAGINARY parts of every GF(p^2) value of element k (each a GF(p)
 // element: 5 signed 26-bit limbs).  Additions are limb-wise on the lane's half; a product a*b is one sum of two GF(p) products
 // per lane -- even lane: a_re*b_re + (-a_im)*b_im, odd lane: a_im*b_re + a_re*b_im -- with the partner's halves fetched by
-// v_mov_b32_dpp quad_perm (no LDS, no waits); a square is one GF(p) product per lane.  A lane issues 1 323 instead of 2 133
-// instructions per ladder step (tools/microbench/pairlane.hip: 0.58 of the step's latency at one wave per SIMD; at two waves
-// per SIMD, i.e. the same elements per chip, it is within +-3 % of the one-lane step, so it is no throughput lever).
+// v_mov_b32_dpp quad_perm (no LDS, no waits); a square is one GF(p) product per lane.  A lane issues 1 454 instead of 2 154
+// instructions per ladder step: 0.66 of the one-lane kernels' latency at one wave per SIMD (profiles/r03_cliff.txt).  At two waves
+// per SIMD, i.e. the same elements per chip, the step is within +-3 % of the one-lane step (tools/microbench/pairlane.hip,
+// profiles/r03_pairlane.txt): a latency lever, not a throughput lever, which is why only small batches and remainders come here.
 //
-// Same formula DAG as curve.hip.h (curve4q.py:109-175, :258-322, :385-442), hence the same residues in the R1 tuple.  Signed
-// flavour throughout (fp127.hip.h): every element type carries the bound B of its limb magnitudes and every product static_asserts
-// its operand and column bounds, as the one-lane code does.
+// Same formula DAG as curve.hip.h (curve4q.py:109-175, :179-185, :228-235, :258-322, :385-462), hence the same residues in the R1
+// tuple and the same affine DH outputs and verdicts.  Signed flavour throughout (fp127.hip.h): every element type carries the bound B
+// of its limb magnitudes and every product static_asserts its operand and column bounds, as the one-lane code does.
 #pragma once
 #include "curve.hip.h"
 #include "recode.hip.h"
