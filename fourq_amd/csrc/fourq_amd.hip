@@ -339,6 +339,7 @@ struct fourq_ctx {
     uint64_t table_shadow[FOURQ_TABLE_WORDS];   // host copies of what table_limbs / comb_limbs currently hold
     uint64_t comb_shadow[FOURQ_COMB_WORDS];
     bool table_staged = false, comb_staged = false;
+    bool comb_known = false;           // comb_shadow holds a caller's table (it survives a change of stream; the device copy is staged again from it)
     hipEvent_t shadow_read = nullptr;   // recorded behind every upload from a shadow: a shadow is rewritten only after its last upload has read it
     u32* part_counter = nullptr;   // mixed batches: number of variable-base elements of the current round (device side)
     u32* part_list = nullptr;      // their ids, split_chunk entries
@@ -1108,11 +1109,18 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
 // The staged comb stays on the device between calls.  fourq_comb_stage does the 106 KB compare-and-upload once; batch calls
 // that pass comb == NULL use what is staged and do no host-side work on the table at all (a non-NULL comb is compared with the
 // staged copy on every call, which costs microseconds of host time per call on the key-generation path).
+// comb == NULL: "the table fourq_comb_stage was given" -- staged again from the shadow if the stream has changed since
 static int stage_comb(fourq_ctx* c, const uint64_t* comb) {
-    if (c->comb_staged && memcmp(c->comb_shadow, comb, sizeof c->comb_shadow) == 0) return FOURQ_OK;      // as stage_table
-    c->comb_staged = false;
-    if (int rc = shadow_free(c)) return rc;
-    memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
+    if (!comb) {
+        if (!c->comb_known) return FOURQ_ERR_INVALID;
+        if (c->comb_staged) return FOURQ_OK;
+    } else {
+        if (c->comb_staged && memcmp(c->comb_shadow, comb, sizeof c->comb_shadow) == 0) return FOURQ_OK;      // as stage_table
+        c->comb_staged = false;
+        if (int rc = shadow_free(c)) return rc;
+        memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
+        c->comb_known = true;
+    }
     HIP_TRY(c, hipMemcpyAsync(c->comb_packed, c->comb_shadow, FOURQ_COMB_WORDS * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipEventRecord(c->shadow_read, c->stream));
     hipLaunchKernelGGL(comb_unpack_kernel, dim3((COMB_POINTS + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, c->stream, c->comb_packed, c->comb_limbs);
@@ -1127,11 +1135,11 @@ FQ_API int fourq_comb_stage(fourq_ctx* c, const uint64_t* comb) {
 }
 FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !scalars || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;      // NULL = "the staged table": there must be one
+    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;       // NULL = "the staged table": there must be one
     if (!aligned16(scalars) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    if (comb) { int rc = stage_comb(c, comb); if (rc) return rc; }
+    if (int rc = stage_comb(c, comb)) return rc;
     const int group = normalize_group(c, n);
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
     if (rc) return rc;
@@ -1145,10 +1153,11 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
 }
 FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !scalars || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;
+    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    if (comb) { int rc = stage_comb(c, comb); if (rc) return rc; comb = nullptr; }      // compared once, not once per chunk
+    if (int rc = stage_comb(c, comb)) return rc;                                        // compared once, not once per chunk
+    comb = nullptr;
     PipeArray in[1] = { { (const char*)scalars, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
@@ -1280,7 +1289,7 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
 // dh_exchange with the key-generation half through the comb (bench.py's cfg4 step as one call)
 FQ_API int fourq_dh_exchange_comb_batch_dev(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !a || !b || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;
+    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
@@ -1296,10 +1305,10 @@ FQ_API int fourq_dh_exchange_comb_batch_dev(fourq_ctx* c, const uint64_t* a, con
 }
 FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !a || !b || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_staged) return FOURQ_ERR_INVALID;
+    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     DeviceGuard g(c->device);
-    if (comb) { int rc = stage_comb(c, comb); if (rc) return rc; }          // compared once, not once per chunk
+    if (int rc = stage_comb(c, comb)) return rc;                            // compared once, not once per chunk
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {

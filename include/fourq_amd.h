@@ -208,7 +208,8 @@ int fourq_decode_batch_dev(fourq_ctx *ctx, const uint8_t *in32, uint64_t *out_af
 int fourq_comb_table(fourq_ctx *ctx, const uint64_t *p_r1, uint64_t *comb);
 /* The device copy of the comb stays staged between calls.  A batch call with a non-NULL `comb` compares it with the staged
  * copy (103.5 KiB on the host, per call) and uploads it when it differs; fourq_comb_stage does that once, and batch calls
- * with comb == NULL then use the staged table without touching it (FOURQ_ERR_INVALID when nothing is staged). */
+ * with comb == NULL then use the staged table without touching it (FOURQ_ERR_INVALID when no table was ever given; after
+ * fourq_ctx_set_stream the context uploads its own copy again by itself on the first use). */
 int fourq_comb_stage(fourq_ctx *ctx, const uint64_t *comb);
 /* status[i]: FOURQ_DH_OK or FOURQ_DH_NEUTRAL ([m]B is the neutral point); out zeroed in that case */
 int fourq_comb_mul_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *comb, uint64_t *out_affine, uint8_t *status, size_t n);

@@ -150,3 +150,11 @@ def test_reserved_context_is_capturable_without_a_warm_up_call(monkeypatch):
         assert np.array_equal(keys.cpu().numpy().view(np.uint64), want_keys)
         assert np.array_equal(shared.cpu().numpy().view(np.uint64), want_shared)
         assert not st1.cpu().numpy().any() and not st2.cpu().numpy().any()
+        # a change of stream drops the device copy of the staged comb, not the table: None still means "the table given to comb_stage"
+        other = torch.cuda.Stream(device=dev)
+        e.set_stream(other.cuda_stream)
+        keys.zero_()
+        torch.cuda.synchronize()
+        e.comb_mul_dev(b, None, keys, st1, n)
+        e.sync()
+        assert np.array_equal(keys.cpu().numpy().view(np.uint64), want_keys)
