@@ -430,18 +430,23 @@ bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
 // generation of elements.  A batch that small runs on them alone; a batch of q generations + r elements, 0 < r <= pair_max, on the
 // fused route runs q fused generations and then the r elements two lanes each, so the element past a generation costs half a
 // generation instead of a whole one.  Both selection modes.
-template <int ALGO, bool DH> int launch_pair(fourq_ctx* c, LadderArgs a) {
+// FIXED: the staged fixed-base table (c->table_limbs) instead of a table built per element.
+template <int ALGO, bool DH, bool FIXED = false> int launch_pair(fourq_ctx* c, LadderArgs a) {
     if (a.n == 0) return FOURQ_OK;
     const size_t blocks = ((size_t)a.n + BLOCK / 2 - 1) / (BLOCK / 2);
     const unsigned grid = (unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus);
+    a.table = c->table_limbs;
     if (c->ct) {                            // fourq_ct_fused.hip: the same kernels with the lane's table scanned at every step
-        HIPRC_TRY(c, ct_launch_pair(ALGO, DH, grid, c->stream, a));
+        HIPRC_TRY(c, ct_launch_pair(ALGO, DH, FIXED, grid, c->stream, a));
         return FOURQ_OK;
     }
-    hipLaunchKernelGGL((pair_kernel<ALGO, DH>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL((pair_kernel<ALGO, DH, false, FIXED>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
 }
+// fixed-base batches of at most half a generation: the same two-lanes-per-element kernels on the caller's table (the LDS ladders
+// of fourq_chain.hip take over above that: one lane per element, up to four waves per SIMD)
+bool fixed_takes_pair(const fourq_ctx* c, size_t n) { return c->pair_max && n <= c->pair_max; }
 // The route of a variable-base batch.  PAIR_TAIL: whole fused generations, then the remainder two lanes per element (also a batch
 // that is nothing but such a remainder).  Below two generations it beats the two-kernel route for every entry point (65 792
 // elements: DH_endo 0.69 against 0.74 ms, MUL_windowed 1.10 against 1.19); from two generations on the two-kernel route's four
@@ -534,6 +539,7 @@ int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
     if (points) return algo == ENDO ? launch_variable<ENDO, false>(c, a) : launch_variable<WINDOWED, false>(c, a);
     int rc = stage_table(c, table);
     if (rc) return rc;
+    if (!index && fixed_takes_pair(c, n)) return algo == ENDO ? launch_pair<ENDO, false, true>(c, a) : launch_pair<WINDOWED, false, true>(c, a);
     return algo == ENDO ? launch_ladder<ENDO, LDS, false>(c, a) : launch_ladder<WINDOWED, LDS, false>(c, a);
 }
 
@@ -545,6 +551,11 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
     DeviceGuard g(c->device);
     LadderArgs a = {};
     a.scalars = scalars; a.points = points; a.out = out; a.status = status; a.n = (u32)n;
+    if (table && fixed_takes_pair(c, n)) {         // small fixed-base DH batches: two lanes per element, inversion in the kernel
+        int rc = stage_table(c, table);
+        if (rc) return rc;
+        return algo == ENDO ? launch_pair<ENDO, true, true>(c, a) : launch_pair<WINDOWED, true, true>(c, a);
+    }
     int group = normalize_group(c, n);
     if (!table) {                                  // fused kernels invert in place; the prep + ladder route always defers
         const bool split = variable_route(c, algo, true, n, false) == ROUTE_SPLIT;

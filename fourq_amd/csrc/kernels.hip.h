@@ -578,7 +578,10 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 // 128 elements per 256-lane block (the pair's table fills the CU's LDS), one block per CU, grid-stride over the batch.  Each lane
 // loads, computes and stores ITS half (real or imaginary parts) of every coordinate; the scalar is recoded in both lanes.
 // CT: constant-time table selection -- the lane scans its eight entries in LDS at every step (PairTable::scan_entry).
-template <int ALGO, bool DH, bool CT = false>
+// FIXED: the caller's table (a.table, working limbs) instead of one built from a point: every lane copies its halves of the
+// eight entries into its LDS rows once, then the same ladders run (with a table the reference ignores the point: curve4q.py:209,
+// :426; DH still tests it, curve4q.py:447-448).
+template <int ALGO, bool DH, bool CT = false, bool FIXED = false>
 __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
     __shared__ __attribute__((aligned(16))) u32 lds_pair[PAIR_LDS_U32];
     PairTable tbl;
@@ -589,6 +592,16 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
     constexpr u32 PER_BLOCK = BLOCK / 2;
     constexpr int IN_WORDS = DH ? 8 : 20, OUT_WORDS = DH ? 8 : 20;
     const u32 n = a.n, n_round = (n + PER_BLOCK - 1) / PER_BLOCK * PER_BLOCK;
+    if constexpr (FIXED) {                       // entry k, coordinate c: 12 dwords = re limbs 0..4 | im limbs 0..4 | 2 pad (load_fe2_limbs)
+#pragma unroll 1
+        for (int v = 0; v < PAIR_VALUES; v++) {
+            const u32* src = a.table + (v >> 2) * R2_LIMBS + (v & 3) * COORD_U32 + 5 * odd;
+            PF<1> h;
+#pragma unroll
+            for (int i = 0; i < 5; i++) { h.l[i] = src[i]; FQ_SIGN_UNKNOWN(h.l[i]); }
+            tbl.put(v, h);
+        }
+    }
 #pragma unroll 1
     for (u32 it = blockIdx.x * PER_BLOCK + (threadIdx.x >> 1); it < n_round; it += gridDim.x * PER_BLOCK) {
         const bool live = it < n;
@@ -611,18 +624,18 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
         if constexpr (DH) {
             const PF<1> x = half(0), y = half(1);
             if (!pair_point_on_curve(x, y, pl)) st = FOURQ_DH_NOT_ON_CURVE;      // keep going branch-free; masked at the end
-            P = pair_clear_cofactor_392(x, y, pl);
-        } else {
+            if constexpr (!FIXED) P = pair_clear_cofactor_392(x, y, pl);
+        } else if constexpr (!FIXED) {
             P.X = half(0); P.Y = half(1); P.Z = half(2); P.Ta = pwiden<3>(half(3)); P.Tb = pwiden<2>(half(4));
         }
         PR1 Q;
         if constexpr (ALGO == ENDO) {
-            pair_build_table_endo(P, tbl, pl);
+            if constexpr (!FIXED) pair_build_table_endo(P, tbl, pl);
             u64 v[4];
             decompose(m, v);
             Q = pair_ladder_endo<CT>(recode(v), tbl, pl);
         } else {
-            pair_build_table_windowed(P, tbl, pl);
+            if constexpr (!FIXED) pair_build_table_windowed(P, tbl, pl);
             Q = pair_ladder_windowed<CT>(win_reduce(m), tbl, pl);
         }
         if constexpr (DH) {
@@ -917,7 +930,7 @@ int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, con
 int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
 // constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
-int ct_launch_pair(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_pair(int algo, bool dh, bool fixed, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
                          u32* over_scratch, u32 lanes, u32 limit);     // split_counts_kernel must already have run: see fourq_ct_chain.hip
 int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit);

@@ -238,6 +238,20 @@ def test_one_lane_and_two_lane_kernels_on_small_batches_and_tails(pair_max, monk
                 got_d, got_st = fn(sc[:m], aff[:m])
                 assert np.array_equal(got_st, want_st[:m]) and np.array_equal(got_d, want_d[:m]), (pair_max, algo, m)
             assert want_st[7] == 1 and want_st[11] == 2
+        # fixed base: the caller's table copied into the lanes' LDS rows (pair_kernel<..., FIXED>) or staged once per block (LDS ladders)
+        te, tw = e.table_endo(codec.pack_point(G1)), e.table_windowed(codec.pack_point(G1))
+        for ct in (False, True):
+            e.ct_select = ct
+            for m in (1, 129, k):
+                assert np.array_equal(e.mul_endo_fixed(sc[:m], te), oc.mul(oc.ENDO, sc[:m], None, te)), (pair_max, ct, m)
+                assert np.array_equal(e.mul_windowed_fixed(sc[:m], tw), oc.mul(oc.WINDOWED, sc[:m], None, tw)), (pair_max, ct, m)
+            for algo, fn, tab in ((oc.ENDO, e.dh_endo, te), (oc.WINDOWED, e.dh_windowed, tw)):
+                want_d, want_st = oc.dh(algo, sc[:k], aff, tab)
+                for m in (12, k):
+                    got_d, got_st = fn(sc[:m], aff[:m], tab)
+                    assert np.array_equal(got_st, want_st[:m]) and np.array_equal(got_d, want_d[:m]), (pair_max, ct, algo, m)
+                assert want_st[7] == 1
+        e.ct_select = False
 
 
 def _kat_p392():
