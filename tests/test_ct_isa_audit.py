@@ -18,9 +18,9 @@ def test_constant_time_kernels_have_no_digit_dependent_address_or_branch(tmp_pat
     rows, problems = ct_isa_audit.audit_units(ct_isa_audit.UNITS, str(tmp_path))
     assert not problems, problems[:5]
     kinds = {name for _, name, loops, _ in rows if loops}
-    assert len(kinds) >= 18                                     # 4 fused + 4 pair-lane + 6 LDS ladders + 2 combs + the mixed-batch queue and tail kernels
-    assert sum(loops for _, _, loops, _ in rows) >= 20
-    assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and loops == 1) == 4
+    assert len(kinds) >= 22                                     # 4 fused + 8 pair-lane + 6 LDS ladders + 2 combs + the mixed-batch queue and tail kernels
+    assert sum(loops for _, _, loops, _ in rows) >= 24
+    assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and loops == 1) == 8      # variable and fixed base x MUL / DH x endo / windowed
     assert any("mixed_ct_tail_kernel" in name and loops == 2 for _, name, loops, _ in rows)     # shared table in LDS / per-lane table in memory
     assert any("mixed_queue_kernel" in name and loops == 2 for _, name, loops, _ in rows)      # both kinds of work item
 
