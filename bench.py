@@ -424,6 +424,40 @@ class Bench:
         return {"op": name, "batch_per_gpu": n, "steps": steps, "ms_per_step": round(ms, 4), "value_per_gpu": round(n / (ms * 1e-3), 1), "unit": "scalar-mults/s",
                 "parity_ok": True, "algorithmic_frac": round(alg * n / (ms * 1e-3) / VALU_MAD_PEAK, 4), "executed_frac": round(mads * n / (ms * 1e-3) / VALU_MAD_PEAK, 4)}
 
+    def size_sweep(self, d, sizes=(1, 1024, 32768, 65536, 65792, 98304), reps=30):
+        """How the headline operation's time depends on the batch size (device-resident, HIP events on the launch stream, median of
+        `reps` back-to-back calls at a sustained clock).  One lane owns one scalar multiplication for a whole ladder, so the chip works
+        in generations of `lanes` elements; batches of at most half a generation and remainders past a generation run two lanes per
+        element (pair.hip.h).  The ratio t(65 792) / t(65 536) is VERDICT r2's measure of the generation cliff."""
+        import torch
+        eng = self.eng
+        scalars = d["keep"][0]
+        points = self.to_dev(d["points_h"])
+        n_all = len(d["scalars_h"])
+        big = max(sizes)
+        if big > n_all:                                   # the sweep's largest size: repeat the batch's inputs
+            reps_in = (big + n_all - 1) // n_all
+            scalars, points = scalars.repeat(reps_in, 1)[:big].contiguous(), points.repeat(reps_in, 1)[:big].contiguous()
+        out = torch.empty((big, 20), dtype=torch.int64, device=self.dev)
+        rec = {}
+        for n in sizes:
+            for _ in range(5):
+                eng.mul_endo_dev(scalars, points, out, n)
+            times = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(self.stream)
+                eng.mul_endo_dev(scalars, points, out, n)
+                b.record(self.stream)
+                torch.cuda.synchronize()
+                times.append(a.elapsed_time(b))
+            rec[str(n)] = round(sorted(times)[len(times) // 2], 4)
+        rec["unit"] = "ms per call of MUL_endo(m, P), variable base, n elements"
+        rec["lanes"] = eng.lanes
+        if "65536" in rec and "65792" in rec:
+            rec["t(65792)/t(65536)"] = round(rec["65792"] / rec["65536"], 3)
+        return rec
+
     def gather_ms(self, out, n, reps=3):
         """The path's only collective: results gathered to rank 0 (RCCL over xGMI; gloo in rehearsals).  Median of `reps`."""
         import torch
@@ -686,6 +720,8 @@ def main():
             line["configs"] = configs
         if world == 1 and not args.no_pcie and want is not None:
             line["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=pcie_reps[args.workload])
+        if world == 1 and args.workload == "cfg2" and not args.batch and not args.no_alongside:
+            line["size_sweep"] = b.size_sweep(d)
         if ct:
             line["ct_select"] = dict(ct, mode="fourq_ctx_set_ct_select(ctx, 1) on a second context: every ladder step reads the whole table and "
                                               "selects by masks; no address depends on the scalar (DESIGN.md section 10); outputs compared with the "
