@@ -185,6 +185,29 @@ def test_host_pipeline_chunks_and_pinned_memory(eng, pinned):
             eng.host_free(arr)
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_small_host_call_runs_in_order_on_the_context_stream(eng, pinned):
+    """A call of one chunk of at most 1 MiB (the reference-shaped call is a batch of one) skips the three-stream pipeline:
+    same results, byte counts reported, copy durations untimed (0); one element more than the limit takes the pipeline."""
+    put = (lambda x: eng.host_array(x)) if pinned else (lambda x: x)
+    te = oc.table(oc.ENDO, codec.pack_point(G1))
+    for n in (1, 7, 2977, 2978):                               # 2977 x (32 + 160 + 160) B in 256-byte-aligned arrays: just under 1 MiB; 2978: just over
+        s = put(seeded_scalars(91, n))
+        pts = put(eng.mul_endo_fixed(seeded_scalars(92, n), te))
+        got = eng.mul_endo(s, pts)
+        st = eng.host_stats()
+        assert np.array_equal(got, oc.mul(oc.ENDO, np.asarray(s), np.asarray(pts)))
+        assert st["chunks"] == 1 and st["h2d_bytes"] == n * 192 and st["d2h_bytes"] == n * 160 and st["pinned_in"] == int(pinned)
+        assert (st["h2d_ms"] == 0 and st["d2h_ms"] == 0) if n <= 2977 else (st["h2d_ms"] > 0 and st["d2h_ms"] > 0)
+        g = put(np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0))
+        out, status = eng.dh_endo(s, g)
+        want, ws = oc.dh(oc.ENDO, np.asarray(s), np.asarray(g))
+        assert np.array_equal(out, want) and np.array_equal(status, ws)
+        if pinned:
+            for arr in (s, pts, g):
+                eng.host_free(arr)
+
+
 def test_set_stream_restages_the_fixed_base_table(eng):
     import torch
     tw = oc.table(oc.WINDOWED, codec.pack_point(G1))
