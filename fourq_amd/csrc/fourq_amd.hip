@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -365,6 +366,7 @@ struct fourq_ctx {
     fourq_host_stats host_stats = {};
     bool host_bounce = true;       // FOURQ_HOST_BOUNCE=0: hand pageable arrays to hipMemcpyAsync directly (measurement knob)
     char err[256] = { 0 };
+    mutable std::recursive_mutex mu;   // CtxGuard: calls on one context take turns
 };
 
 namespace {
@@ -379,6 +381,16 @@ struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+// What every entry point holds for its duration: the context's lock, then the context's device.  The reference's functions are
+// pure (curve4q.py), so a drop-in caller may well call them from several threads at once -- fourq_amd.curve4q does so on ONE
+// process-wide context -- while a context is one stream, one set of scratch slots and one set of pipeline buffers.  Calls on the
+// same context therefore take turns (host-array calls for their whole duration, _dev calls for their enqueue); contexts are
+// independent of each other.  Recursive, because host-array entry points are built from the _dev ones.
+struct CtxGuard {
+    std::unique_lock<std::recursive_mutex> lock;
+    DeviceGuard dev;
+    explicit CtxGuard(const fourq_ctx* c) : lock(c->mu), dev(c->device) {}
 };
 
 int ensure_stage(fourq_ctx* c, size_t bytes) {
@@ -533,7 +545,7 @@ int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
     if (!c || !scalars || !out || (!points && !table) || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(out) || !aligned16(points)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     LadderArgs a = {};
     a.scalars = scalars; a.points = points; a.out = out; a.index = index; a.n = (u32)n;
     if (points) return algo == ENDO ? launch_variable<ENDO, false>(c, a) : launch_variable<WINDOWED, false>(c, a);
@@ -548,7 +560,7 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
     if (!c || !scalars || !points || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(points) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     LadderArgs a = {};
     a.scalars = scalars; a.points = points; a.out = out; a.status = status; a.n = (u32)n;
     if (table && fixed_takes_pair(c, n)) {         // small fixed-base DH batches: two lanes per element, inversion in the kernel
@@ -760,7 +772,7 @@ size_t pipe_chunk(const fourq_ctx* c, bool fused_route) { return fused_route ? c
 int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out, size_t n) {
     if (!c || !scalars || !out || (!points && !table) || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points, nullptr, 160 } };
     PipeArray o[1] = { { nullptr, (char*)out, 160 } };
     // variable-base MUL_endo: chunks of one fused generation overlap the copies better than rounds of the two-kernel route
@@ -774,7 +786,7 @@ int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
             uint8_t* status, size_t n) {
     if (!c || !scalars || !points || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points, nullptr, 64 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     const bool fused = !table && !takes_split_route(c, algo, true, n);
@@ -785,7 +797,7 @@ int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
 
 int table_host(fourq_ctx* c, int algo, const uint64_t* p_r1, uint64_t* table) {
     if (!c || !p_r1 || !table) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     int rc = ensure_stage(c, 160);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->stage, p_r1, 160, hipMemcpyHostToDevice, c->stream));
@@ -905,6 +917,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
 
 FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (!c) return FOURQ_ERR_INVALID;
+    { CtxGuard last(c); }                      // a call still running on another thread finishes first; the caller must not start new ones
     DeviceGuard g(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -938,6 +951,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
 
 FQ_API int fourq_ctx_set_stream(fourq_ctx* c, void* hip_stream) {
     if (!c) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     if (next != c->stream) {
         // the staged fixed-base / comb tables were unpacked by launches on the old stream: nothing orders the new
@@ -950,6 +964,7 @@ FQ_API int fourq_ctx_set_stream(fourq_ctx* c, void* hip_stream) {
 }
 FQ_API int fourq_ctx_set_ct_select(fourq_ctx* c, int on) {
     if (!c) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
     c->ct = on != 0;
     return FOURQ_OK;
 }
@@ -960,7 +975,7 @@ FQ_API int fourq_ctx_get_ct_select(const fourq_ctx* c, int* on) {
 }
 FQ_API int fourq_ctx_sync(fourq_ctx* c) {
     if (!c) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FOURQ_OK;
 }
@@ -969,7 +984,7 @@ FQ_API int fourq_ctx_sync(fourq_ctx* c) {
 // synchronises the stream and reallocates inside the call (not capturable into a graph).
 FQ_API int fourq_ctx_reserve(fourq_ctx* c, size_t n) {
     if (!c || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     int rc = ensure_proj(c, n);
     if (rc) return rc;
     const size_t a = dh_bytes_work_bytes(n), b = exchange_work_bytes(n);
@@ -983,26 +998,26 @@ FQ_API int fourq_ctx_lanes(const fourq_ctx* c, size_t* lanes) {
 
 FQ_API int fourq_dev_alloc(fourq_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     HIP_TRY(c, hipMalloc(out, bytes ? bytes : 16));
     return FOURQ_OK;
 }
 FQ_API int fourq_dev_free(fourq_ctx* c, void* ptr) {
     if (!c) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     HIP_TRY(c, hipFree(ptr));
     return FOURQ_OK;
 }
 FQ_API int fourq_dev_upload(fourq_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FOURQ_OK;
 }
 FQ_API int fourq_dev_download(fourq_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FOURQ_OK;
@@ -1041,7 +1056,7 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     if (!c || !s || !p || !flags || !table || !o || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(s) || !aligned16(p) || !aligned16(o)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     int rc = stage_table(c, table);
     if (rc) return rc;
     // Rounds of up to split_chunk elements.  Per round: compact the variable-base ids (count stays on the device),
@@ -1103,7 +1118,7 @@ FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uin
                                       const uint64_t* table, uint64_t* o, size_t n) {
     if (!c || !s || !p || !flags || !table || !o || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     PipeArray in[3] = { { (const char*)s, nullptr, 32 }, { (const char*)p, nullptr, 160 }, { (const char*)flags, nullptr, 1 } };
     PipeArray out[1] = { { nullptr, (char*)o, 160 } };
     return run_pipeline(c, in, 3, out, 1, n, c->split_chunk, [&](char* const* di, char* const* dout, size_t m) {
@@ -1126,7 +1141,7 @@ FQ_API int fourq_dh_windowed_batch_dev(fourq_ctx* c, const uint64_t* s, const ui
 
 FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) {
     if (!c || !p_r1 || !comb) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     int rc = ensure_stage(c, 160);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->stage, p_r1, 160, hipMemcpyHostToDevice, c->stream));
@@ -1160,7 +1175,7 @@ static int stage_comb(fourq_ctx* c, const uint64_t* comb) {
 }
 FQ_API int fourq_comb_stage(fourq_ctx* c, const uint64_t* comb) {
     if (!c || !comb) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     return stage_comb(c, comb);
 }
 FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
@@ -1168,7 +1183,7 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;       // NULL = "the staged table": there must be one
     if (!aligned16(scalars) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     if (int rc = stage_comb(c, comb)) return rc;
     const int group = normalize_group(c, n);
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
@@ -1185,7 +1200,7 @@ FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uin
     if (!c || !scalars || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     if (int rc = stage_comb(c, comb)) return rc;                                        // compared once, not once per chunk
     comb = nullptr;
     PipeArray in[1] = { { (const char*)scalars, nullptr, 32 } };
@@ -1198,7 +1213,7 @@ FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uin
 FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {
     if (!c || !affine || !out32 || n > FOURQ_MAX_BATCH || !aligned16(affine) || !aligned16(out32)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, affine, (u64*)out32, (u32)n);
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
@@ -1206,7 +1221,7 @@ FQ_API int fourq_encode_batch_dev(fourq_ctx* c, const uint64_t* affine, uint8_t*
 FQ_API int fourq_decode_batch_dev(fourq_ctx* c, const uint8_t* in32, uint64_t* affine, uint8_t* status, size_t n) {
     if (!c || !in32 || !affine || !status || n > FOURQ_MAX_BATCH || !aligned16(in32) || !aligned16(affine)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, (const u64*)in32, affine, status, (u32)n);
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
@@ -1214,7 +1229,7 @@ FQ_API int fourq_decode_batch_dev(fourq_ctx* c, const uint8_t* in32, uint64_t* a
 FQ_API int fourq_encode_batch(fourq_ctx* c, const uint64_t* affine, uint8_t* out32, size_t n) {
     if (!c || !affine || !out32 || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     PipeArray in[1] = { { (const char*)affine, nullptr, 64 } };
     PipeArray o[1] = { { nullptr, (char*)out32, 32 } };
     return run_pipeline(c, in, 1, o, 1, n, 4 * c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
@@ -1224,7 +1239,7 @@ FQ_API int fourq_encode_batch(fourq_ctx* c, const uint64_t* affine, uint8_t* out
 FQ_API int fourq_decode_batch(fourq_ctx* c, const uint8_t* in32, uint64_t* affine, uint8_t* status, size_t n) {
     if (!c || !in32 || !affine || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     PipeArray in[1] = { { (const char*)in32, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)affine, 64 }, { nullptr, (char*)status, 1 } };
     return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
@@ -1239,7 +1254,7 @@ static int dh_bytes_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const u
     if (!c || !scalars || !keys32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(keys32) || !aligned16(out32)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     const size_t nb = align256(n);
     int rc = ensure_work(c, dh_bytes_work_bytes(n));
     if (rc) return rc;
@@ -1258,7 +1273,7 @@ static int dh_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const 
                          uint8_t* status, size_t n) {
     if (!c || !scalars || !keys32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)keys32, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out32, 32 }, { nullptr, (char*)status, 1 } };
     const bool fused = !table && !takes_split_route(c, algo, true, n);
@@ -1285,7 +1300,7 @@ FQ_API int fourq_dh_exchange_batch_dev(fourq_ctx* c, const uint64_t* a, const ui
     if (!c || !a || !b || !base_affine || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     int rc = ensure_work(c, exchange_work_bytes(n));
     if (rc) return rc;
     uint64_t* base = (uint64_t*)c->work;                      // the base point, once per exchange
@@ -1306,7 +1321,7 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
                                    uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !a || !b || !base_affine || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     uint64_t base_copy[8];
     memcpy(base_copy, base_affine, sizeof base_copy);         // the caller's buffer is read once, here
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
@@ -1322,7 +1337,7 @@ FQ_API int fourq_dh_exchange_comb_batch_dev(fourq_ctx* c, const uint64_t* a, con
     if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     int rc = ensure_work(c, exchange_work_bytes(n));
     if (rc) return rc;
     uint64_t* mid = (uint64_t*)(c->work + n * 64);            // [b_i]B: the public keys (same place as in fourq_dh_exchange_batch_dev)
@@ -1337,7 +1352,7 @@ FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const u
     if (!c || !a || !b || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     if (int rc = stage_comb(c, comb)) return rc;                            // compared once, not once per chunk
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
@@ -1349,13 +1364,13 @@ FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const u
 // ---- pinned host memory and transfer statistics of the host-pointer calls ---------------------------------------
 FQ_API int fourq_host_alloc(fourq_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     HIP_TRY(c, hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
     return FOURQ_OK;
 }
 FQ_API int fourq_host_free(fourq_ctx* c, void* ptr) {
     if (!c) return FOURQ_ERR_INVALID;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     HIP_TRY(c, hipHostFree(ptr));
     return FOURQ_OK;
 }
@@ -1375,7 +1390,7 @@ FQ_API int fourq_prim_batch(fourq_ctx* c, int op, const uint64_t* in, uint64_t* 
     const PrimShape* p = find_prim(op);
     if (!c || !p || !in || !out || n > 0x7fffffffu) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
-    DeviceGuard g(c->device);
+    CtxGuard g(c);
     size_t ib = n * p->in_words * 8, ob = n * p->out_words * 8;
     int rc = ensure_stage(c, ib + ob);
     if (rc) return rc;

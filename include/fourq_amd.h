@@ -78,6 +78,12 @@ const char *fourq_last_error(const fourq_ctx *ctx);   /* detail of the last FOUR
  * contiguous shards, no exchange step; fourq_amd/multi.py (MultiEngine) is the host-side loop over them. */
 int fourq_device_count(int *count);
 int fourq_ctx_create(int device, fourq_ctx **out);
+/* Threads.  Every entry point that takes a context holds that context's lock for its duration, so calls made on ONE context
+ * from several threads are safe and take turns (a host-array call for its whole duration, a _dev call for its enqueue); the
+ * reference's functions are pure, and a drop-in caller may use them from any thread.  Calls on different contexts run side by
+ * side (fourq_amd/multi.py: one context and one host thread per device).  What stays per context and is therefore "of the last
+ * call, whoever made it": fourq_last_error, fourq_ctx_host_stats, the stream and mode switches.  fourq_ctx_destroy waits for a
+ * call in flight; starting another one after it is the caller's error. */
 int fourq_ctx_destroy(fourq_ctx *ctx);
 /* Use the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores the
  * context's own stream.  The context never synchronises an external stream behind the caller's back. */

@@ -116,3 +116,56 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert line["gather_ms"] > 0 and line["scaling"] == "weak"
     assert abs(line["value"] - 2 * (1 << 16) / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.01     # whole-job units / max-over-ranks time
     assert line["parity"]["c_oracle_threads"] >= 1                                                      # each rank took a share of the cores
+
+
+def test_one_context_called_from_several_threads():
+    """The reference's functions are pure, so a drop-in caller may use them from any thread; `fourq_amd.curve4q` runs them all on one
+    process-wide context.  Calls on one context take turns under the context's lock (include/fourq_amd.h, "Threads"): eight threads
+    mixing single reference-shaped calls, small and pipelined host-array batches, DH and device-pointer calls on ONE engine, every
+    result compared with the C oracle.  (ctypes drops the GIL for the duration of a call, so the calls do overlap in time.)"""
+    import threading
+    import torch
+    import oracle_c as oc
+    from bench import seeded_scalars
+    from fourq_amd import Engine, codec, constants, curve4q
+    from fourq_amd.engine import default_engine
+    eng = default_engine()
+    g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
+    te = oc.table(oc.ENDO, g1)
+    G = codec.pack_point((constants.Gx, constants.Gy))
+    sizes = [1, 3, 700, 5000, eng.lanes // 2 + 5, eng.lanes + 17, 2 * eng.lanes + 9, 40]
+    errors = []
+
+    def work(t):
+        try:
+            n = sizes[t]
+            for rep in range(3):
+                s, k = seeded_scalars(1000 + 10 * t + rep, n), seeded_scalars(2000 + 10 * t + rep, n)
+                pts = eng.mul_endo_fixed(k, te)
+                assert np.array_equal(pts, oc.mul(oc.ENDO, k, None, te)), "fixed"
+                assert np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts)), "variable"
+                m = min(n, 3000)
+                g = np.repeat(G.reshape(1, 8), m, axis=0)
+                out, st = eng.dh_endo(s[:m], g)
+                want, ws = oc.dh(oc.ENDO, s[:m], g)
+                assert np.array_equal(out, want) and np.array_equal(st, ws), "dh"
+                if t % 2:                                              # device-pointer calls from this thread, on the shared context's stream
+                    dev = torch.device("cuda", 0)
+                    s_d, p_d = torch.from_numpy(s.view(np.int64)).to(dev), torch.from_numpy(pts.view(np.int64)).to(dev)
+                    o_d = torch.empty((n, 20), dtype=torch.int64, device=dev)
+                    torch.cuda.synchronize()
+                    eng.mul_windowed_dev(s_d, p_d, o_d, n)
+                    eng.sync()
+                    assert np.array_equal(o_d.cpu().numpy().view(np.uint64), oc.mul(oc.WINDOWED, s, pts)), "dev"
+                mi = int.from_bytes(s[0].tobytes(), "little")
+                P = codec.unpack_fp2s(pts[0])
+                assert curve4q.MUL_endo(mi, P) == codec.unpack_fp2s(oc.mul(oc.ENDO, s[:1], pts[:1])[0]), "single"
+        except BaseException as e:                                     # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(len(sizes))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
