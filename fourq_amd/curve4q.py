@@ -13,9 +13,12 @@ use `fourq_amd.Engine` (or the `*_batch` helpers below) for throughput.
     DBL :138, ADD_core :155, ADD :174, tau :258, tau_dual :269, upsilon :282, chi :304,
     phi :318, psi :321, decompose :339, recode :358
 """
+import os
+
 import numpy as np
 
 from . import codec
+from .combine import Combiner
 from .constants import N, Gx, Gy, Ox, Oy, d, P127  # noqa: F401  (re-exported, as the reference does)
 from .engine import default_engine
 from .fields import GFp, GFp2  # noqa: F401
@@ -189,26 +192,54 @@ def _check_endo_scalar(m):
     return m
 
 
-def MUL_windowed(m, P, table=None):
-    (X, Y, Z, Ta, Tb) = P                                  # shape check, curve4q.py:190
-    s = codec.pack_scalars([_reduce_windowed(m)])
+# Single variable-base calls made from several threads at once go to the GPU as ONE batch (fourq_amd/combine.py): the calls that
+# arrive while a batch is running are taken along by the next one.  A lone call is not delayed.  FOURQ_COMBINE=0 turns it off.
+_COMBINE = os.environ.get("FOURQ_COMBINE", "1") != "0"
+_combiners = {}
+
+
+def _combined(kind, *rows):
+    """rows: this call's packed arguments, each (1, words).  Returns this call's (output row, status or None)."""
+    cb = _combiners.get(kind)
+    if cb is None:
+        cb = _combiners.setdefault(kind, Combiner(lambda items, kind=kind: _run_batch(kind, items)))
+    return cb(*rows)
+
+
+def _run_batch(kind, items):
+    eng = default_engine()
+    cols = [np.concatenate(c) if len(items) > 1 else c[0] for c in zip(*items)]
+    if kind[0] == "mul":
+        out = (eng.mul_endo if kind[1] == "endo" else eng.mul_windowed)(*cols)
+        return [(out[i], None) for i in range(len(items))]
+    out, status = (eng.dh_endo if kind[1] == "endo" else eng.dh_windowed)(*cols)
+    return [(out[i], int(status[i])) for i in range(len(items))]
+
+
+def combine_stats():
+    """{kind: {"calls", "batches", "largest_batch"}} of the combined single calls so far."""
+    return {"%s_%s" % k: cb.stats() for k, cb in list(_combiners.items())}
+
+
+def _mul(kind, s, P, table):
     eng = default_engine()
     if table:                                              # `if not T` in the reference, curve4q.py:211
-        out = eng.mul_windowed_fixed(s, codec.pack_table(table))
+        out = (eng.mul_endo_fixed if kind == "endo" else eng.mul_windowed_fixed)(s, codec.pack_table(table))[0]
+    elif _COMBINE:
+        out, _ = _combined(("mul", kind), s, codec.pack_point(P).reshape(1, 20))
     else:
-        out = eng.mul_windowed(s, codec.pack_point(P).reshape(1, 20))
-    return codec.unpack_fp2s(out[0])
+        out = (eng.mul_endo if kind == "endo" else eng.mul_windowed)(s, codec.pack_point(P).reshape(1, 20))[0]
+    return codec.unpack_fp2s(out)
+
+
+def MUL_windowed(m, P, table=None):
+    (X, Y, Z, Ta, Tb) = P                                  # shape check, curve4q.py:190
+    return _mul("windowed", codec.pack_scalars([_reduce_windowed(m)]), P, table)
 
 
 def MUL_endo(m, P, table=None):
     (X, Y, Z, Ta, Tb) = P                                  # shape check, curve4q.py:407
-    s = codec.pack_scalars([_check_endo_scalar(m)])
-    eng = default_engine()
-    if table:
-        out = eng.mul_endo_fixed(s, codec.pack_table(table))
-    else:
-        out = eng.mul_endo(s, codec.pack_point(P).reshape(1, 20))
-    return codec.unpack_fp2s(out[0])
+    return _mul("endo", codec.pack_scalars([_check_endo_scalar(m)]), P, table)
 
 
 def MUL_windowed_batch(ms, Ps=None, table=None):
@@ -232,11 +263,14 @@ def _dh(kind, m, P, table):
     eng = default_engine()
     s = codec.pack_scalars([_reduce_windowed(m) if kind == "windowed" else _check_endo_scalar(m)])
     pts = codec.pack_point((X, Y)).reshape(1, 8)
-    t = codec.pack_table(table) if table else None
-    out, status = (eng.dh_windowed if kind == "windowed" else eng.dh_endo)(s, pts, t)
-    if status[0]:
-        raise Exception(_MSG[int(status[0])])
-    return codec.unpack_fp2s(out[0])
+    if table or not _COMBINE:
+        out, status = (eng.dh_windowed if kind == "windowed" else eng.dh_endo)(s, pts, codec.pack_table(table) if table else None)
+        out, status = out[0], int(status[0])
+    else:
+        out, status = _combined(("dh", kind), s, pts)
+    if status:
+        raise Exception(_MSG[status])
+    return codec.unpack_fp2s(out)
 
 
 def DH_core(m, P, mul, table=None):

@@ -1,0 +1,131 @@
+"""fourq_amd.combine.Combiner: concurrent single calls leave as one batch (host logic, no GPU).
+
+The runner here is a stand-in that records the batches it is given; the GPU side of the same mechanism is
+tests/test_gpu_multi.py::test_concurrent_single_calls_are_combined."""
+import threading
+import time
+
+import pytest
+
+from fourq_amd.combine import Combiner
+
+
+def test_lone_calls_are_batches_of_one_and_keep_order_of_results():
+    seen = []
+
+    def run(items):
+        seen.append(list(items))
+        return [a + b for a, b in items]
+
+    cb = Combiner(run)
+    assert [cb(i, 10 * i) for i in range(5)] == [11 * i for i in range(5)]
+    assert seen == [[(i, 10 * i)] for i in range(5)]
+    assert cb.stats() == {"calls": 5, "batches": 5, "largest_batch": 1}
+
+
+def test_calls_arriving_while_a_batch_runs_leave_together():
+    gate, first_in = threading.Event(), threading.Event()
+    sizes = []
+
+    def run(items):
+        sizes.append(len(items))
+        if len(sizes) == 1:
+            first_in.set()
+            assert gate.wait(30)                      # the first batch "is on the GPU" until every other caller has queued
+        return [x * x for (x,) in items]
+
+    cb = Combiner(run)
+    results = {}
+
+    def call(x):
+        results[x] = cb(x)
+
+    t0 = threading.Thread(target=call, args=(0,))
+    t0.start()
+    assert first_in.wait(30)
+    others = [threading.Thread(target=call, args=(x,)) for x in range(1, 41)]
+    for t in others:
+        t.start()
+    deadline = time.time() + 30
+    while len(cb._queue) < 40 and time.time() < deadline:
+        time.sleep(0.001)
+    assert len(cb._queue) == 40
+    gate.set()
+    for t in [t0] + others:
+        t.join(30)
+    assert results == {x: x * x for x in range(41)}
+    assert sizes == [1, 40] and cb.stats() == {"calls": 41, "batches": 2, "largest_batch": 40}
+    assert not cb._busy and not cb._queue
+
+
+def test_max_batch_and_handing_on_of_the_lead():
+    gate, first_in = threading.Event(), threading.Event()
+    sizes, leaders = [], []
+
+    def run(items):
+        sizes.append(len(items))
+        leaders.append(threading.current_thread().name)
+        if len(sizes) == 1:
+            first_in.set()
+            assert gate.wait(30)
+        return [x for (x,) in items]
+
+    cb = Combiner(run, max_batch=16)
+    out = []
+    threads = [threading.Thread(target=lambda x=x: out.append(cb(x)), name="t%d" % x) for x in range(41)]
+    threads[0].start()
+    assert first_in.wait(30)
+    for t in threads[1:]:
+        t.start()
+    deadline = time.time() + 30
+    while len(cb._queue) < 40 and time.time() < deadline:
+        time.sleep(0.001)
+    gate.set()
+    for t in threads:
+        t.join(30)
+    assert sorted(out) == list(range(41)) and sizes == [1, 16, 16, 8]
+    assert len(set(leaders)) == 4                       # four batches, four different leaders: nobody works for others twice
+    assert not cb._busy and not cb._queue
+
+
+def test_errors_reach_the_right_callers():
+    def run(items):
+        if any(x == 13 for (x,) in items):
+            raise RuntimeError("whole batch failed")
+        return [ValueError("odd %d" % x) if x & 1 else x for (x,) in items]
+
+    cb = Combiner(run)
+    assert cb(4) == 4
+    with pytest.raises(ValueError, match="odd 7"):
+        cb(7)
+    with pytest.raises(RuntimeError, match="whole batch"):
+        cb(13)
+    assert cb(6) == 6 and not cb._busy                  # the combiner is usable after either kind of failure
+
+    def bad(items):
+        return []
+
+    with pytest.raises(RuntimeError, match="0 results for 1 calls"):
+        Combiner(bad)(1)
+
+
+def test_many_threads_many_calls():
+    def run(items):
+        time.sleep(0.0005)
+        return [a * b for a, b in items]
+
+    cb = Combiner(run)
+    bad = []
+
+    def work(t):
+        for i in range(200):
+            if cb(t, i) != t * i:
+                bad.append((t, i))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    st = cb.stats()
+    assert not bad and st["calls"] == 3200 and st["batches"] < 3200 and 1 < st["largest_batch"] <= 16

@@ -169,3 +169,51 @@ def test_one_context_called_from_several_threads():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_concurrent_single_calls_are_combined():
+    """`curve4q.MUL_endo(m, P)` etc. from 16 threads: the calls that arrive while a batch is on the GPU leave as one batch
+    (fourq_amd/combine.py); every caller gets its own result -- and its own exception: one thread's DH calls are made on a point
+    that is not on the curve and raise there, and only there."""
+    import threading
+    import oracle_c as oc
+    from bench import seeded_scalars
+    from fourq_amd import codec, constants, curve4q
+    T, R = 16, 25
+    g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
+    te = oc.table(oc.ENDO, g1)
+    s, k = seeded_scalars(3001, T * R), seeded_scalars(3002, T * R)
+    pts = oc.mul(oc.ENDO, k, None, te)
+    want_e, want_w = oc.mul(oc.ENDO, s, pts), oc.mul(oc.WINDOWED, s, pts)
+    g = np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), T * R, axis=0)
+    want_dh, st = oc.dh(oc.ENDO, s, g)
+    assert not st.any()
+    ints = [int.from_bytes(row.tobytes(), "little") for row in s]
+    tuples = [codec.unpack_fp2s(row) for row in pts]
+    before = {kind: v["calls"] for kind, v in curve4q.combine_stats().items()}
+    errors = []
+
+    def work(t):
+        try:
+            for r in range(R):
+                i = t * R + r
+                assert curve4q.MUL_endo(ints[i], tuples[i]) == codec.unpack_fp2s(want_e[i]), "MUL_endo"
+                if r % 5 == 0:
+                    assert curve4q.MUL_windowed(ints[i], tuples[i]) == codec.unpack_fp2s(want_w[i]), "MUL_windowed"
+                if t == 3:
+                    with pytest.raises(Exception, match="Point not on curve"):
+                        curve4q.DH_endo(ints[i], ((1, 2), (3, 4)))
+                else:
+                    assert curve4q.DH_endo(ints[i], (constants.Gx, constants.Gy)) == codec.unpack_fp2s(want_dh[i]), "DH_endo"
+        except BaseException as e:                                     # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    stats = curve4q.combine_stats()
+    assert stats["mul_endo"]["calls"] - before.get("mul_endo", 0) == T * R and stats["dh_endo"]["calls"] - before.get("dh_endo", 0) == T * R
+    assert stats["mul_endo"]["batches"] < stats["mul_endo"]["calls"] and stats["mul_endo"]["largest_batch"] > 1

@@ -23,3 +23,19 @@ for n in (1, 64, 1024, 16384):
     t0 = time.perf_counter()
     for _ in range(100): eng.mul_endo(ss, pp)
     print("Engine.mul_endo n=%-6d      %.3f ms per call" % (n, (time.perf_counter() - t0) / 100 * 1e3))
+
+# the same single calls from 16 threads: combined into batches (fourq_amd/combine.py) vs one launch per call taking turns
+import threading
+for combine in (False, True):
+    curve4q._COMBINE = combine
+    T, R = 16, 200
+    def work():
+        for _ in range(R): curve4q.MUL_endo(m, P)
+    work()
+    ths = [threading.Thread(target=work) for _ in range(T)]
+    t0 = time.perf_counter()
+    for th in ths: th.start()
+    for th in ths: th.join()
+    dt = time.perf_counter() - t0
+    print("curve4q.MUL_endo from %d threads, combine %-5s  %8.0f calls/s  (%.3f ms per call seen by a thread)" % (T, combine, T * R / dt, dt / R * 1e3))
+print("combine_stats", curve4q.combine_stats())
