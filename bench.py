@@ -424,11 +424,12 @@ class Bench:
         return {"op": name, "batch_per_gpu": n, "steps": steps, "ms_per_step": round(ms, 4), "value_per_gpu": round(n / (ms * 1e-3), 1), "unit": "scalar-mults/s",
                 "parity_ok": True, "algorithmic_frac": round(alg * n / (ms * 1e-3) / VALU_MAD_PEAK, 4), "executed_frac": round(mads * n / (ms * 1e-3) / VALU_MAD_PEAK, 4)}
 
-    def size_sweep(self, d, sizes=(1, 1024, 32768, 65536, 65792, 98304), reps=30):
+    def size_sweep(self, d, sizes=(1, 1024, 16384, 32768, 65536, 65792, 98304), reps=30):
         """How the headline operation's time depends on the batch size (device-resident, HIP events on the launch stream, median of
         `reps` back-to-back calls at a sustained clock).  One lane owns one scalar multiplication for a whole ladder, so the chip works
         in generations of `lanes` elements; batches of at most half a generation and remainders past a generation run two lanes per
-        element (pair.hip.h).  The ratio t(65 792) / t(65 536) is VERDICT r2's measure of the generation cliff."""
+        element, those of at most a quarter generation four (pair.hip.h).  The ratio t(65 792) / t(65 536) is VERDICT r2's measure of
+        the generation cliff."""
         import torch
         eng = self.eng
         scalars = d["keep"][0]

@@ -348,6 +348,7 @@ struct fourq_ctx {
     u32* part_fix = nullptr;       // constant-time mode: ids of the round's fixed-base elements
     bool ct = false;               // constant-time table selection (FOURQ_CT_SELECT / fourq_ctx_set_ct_select)
     int mixed_queue = -1;          // mixed batches through the persistent work-queue kernel: 1 always, 0 never, -1 = where it measured faster
+    size_t quad_max = 0;           // ... and of at most this many, four lanes per element (a quarter generation fills the chip)
     size_t pair_max = 0;           // variable-base batches (and tails past whole generations) of at most this many elements run two lanes per element
     uint4* proj = nullptr;         // deferred normalisation of DH batches: PROJ_PLANES planes of proj_capacity uint4, grown on demand
     size_t proj_capacity = 0;
@@ -442,17 +443,22 @@ bool takes_split_route(const fourq_ctx* c, int algo, bool dh, size_t n) {
 // generation of elements.  A batch that small runs on them alone; a batch of q generations + r elements, 0 < r <= pair_max, on the
 // fused route runs q fused generations and then the r elements two lanes each, so the element past a generation costs half a
 // generation instead of a whole one.  Both selection modes.
+// At most quad_max (a QUARTER generation) elements: FOUR lanes per element -- the element's two pairs take every other product of a
+// formula level in the ladder steps -- 0.73 of the two-lane latency again (profiles/r03_quadlane.txt).
 // FIXED: the staged fixed-base table (c->table_limbs) instead of a table built per element.
 template <int ALGO, bool DH, bool FIXED = false> int launch_pair(fourq_ctx* c, LadderArgs a) {
     if (a.n == 0) return FOURQ_OK;
-    const size_t blocks = ((size_t)a.n + BLOCK / 2 - 1) / (BLOCK / 2);
+    const bool quad = a.n <= c->quad_max;   // at most a quarter generation: four lanes per element, the ladder steps' products shared between two pairs
+    const size_t per_block = BLOCK / (quad ? 4 : 2);
+    const size_t blocks = ((size_t)a.n + per_block - 1) / per_block;
     const unsigned grid = (unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus);
     a.table = c->table_limbs;
     if (c->ct) {                            // fourq_ct_fused.hip: the same kernels with the lane's table scanned at every step
-        HIPRC_TRY(c, ct_launch_pair(ALGO, DH, FIXED, grid, c->stream, a));
+        HIPRC_TRY(c, ct_launch_pair(ALGO, DH, FIXED, quad, grid, c->stream, a));
         return FOURQ_OK;
     }
-    hipLaunchKernelGGL((pair_kernel<ALGO, DH, false, FIXED>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
+    if (quad) hipLaunchKernelGGL((pair_kernel<ALGO, DH, false, FIXED, 4>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
+    else hipLaunchKernelGGL((pair_kernel<ALGO, DH, false, FIXED>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
 }
@@ -891,6 +897,8 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = getenv("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
         c->pair_max = c->lanes / 2;                        // two lanes per element: half a generation fills the chip
         if (const char* env = getenv("FOURQ_PAIR_MAX")) { long v = atol(env); if (v >= 0 && (size_t)v <= c->lanes / 2) c->pair_max = (size_t)v; }
+        c->quad_max = c->pair_max < c->lanes / 4 ? c->pair_max : c->lanes / 4;
+        if (const char* env = getenv("FOURQ_QUAD_MAX")) { long v = atol(env); if (v >= 0 && (size_t)v <= c->quad_max) c->quad_max = (size_t)v; }
         if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
         c->split_chunk = c->lanes_w4;
         if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }

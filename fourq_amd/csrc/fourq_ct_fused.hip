@@ -20,15 +20,18 @@ int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const 
 }
 
 namespace {
-template <int ALGO, bool DH> int launch_pair_ct(bool fixed, unsigned grid, hipStream_t stream, const LadderArgs& a) {
-    if (fixed) hipLaunchKernelGGL((pair_kernel<ALGO, DH, true, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((pair_kernel<ALGO, DH, true, false>), dim3(grid), dim3(BLOCK), 0, stream, a);
+template <int ALGO, bool DH, int LPE> int launch_pair_ct(bool fixed, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    if (fixed) hipLaunchKernelGGL((pair_kernel<ALGO, DH, true, true, LPE>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((pair_kernel<ALGO, DH, true, false, LPE>), dim3(grid), dim3(BLOCK), 0, stream, a);
     return (int)hipGetLastError();
 }
+template <int LPE> int launch_pair_ct_lpe(int algo, bool dh, bool fixed, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    if (algo == ENDO) return dh ? launch_pair_ct<ENDO, true, LPE>(fixed, grid, stream, a) : launch_pair_ct<ENDO, false, LPE>(fixed, grid, stream, a);
+    return dh ? launch_pair_ct<WINDOWED, true, LPE>(fixed, grid, stream, a) : launch_pair_ct<WINDOWED, false, LPE>(fixed, grid, stream, a);
+}
 }  // namespace
-int ct_launch_pair(int algo, bool dh, bool fixed, unsigned grid, hipStream_t stream, const LadderArgs& a) {
-    if (algo == ENDO) return dh ? launch_pair_ct<ENDO, true>(fixed, grid, stream, a) : launch_pair_ct<ENDO, false>(fixed, grid, stream, a);
-    return dh ? launch_pair_ct<WINDOWED, true>(fixed, grid, stream, a) : launch_pair_ct<WINDOWED, false>(fixed, grid, stream, a);
+int ct_launch_pair(int algo, bool dh, bool fixed, bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    return quad ? launch_pair_ct_lpe<4>(algo, dh, fixed, grid, stream, a) : launch_pair_ct_lpe<2>(algo, dh, fixed, grid, stream, a);
 }
 int ct_launch_mixed_queue(unsigned grid, hipStream_t stream, const LadderArgs& a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head) {
     hipLaunchKernelGGL(mixed_queue_kernel<true>, dim3(grid), dim3(BLOCK), 0, stream, a, var_list, fix_list, counts, queue_head);

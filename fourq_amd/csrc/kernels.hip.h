@@ -581,15 +581,21 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 // FIXED: the caller's table (a.table, working limbs) instead of one built from a point: every lane copies its halves of the
 // eight entries into its LDS rows once, then the same ladders run (with a table the reference ignores the point: curve4q.py:209,
 // :426; DH still tests it, curve4q.py:447-448).
-template <int ALGO, bool DH, bool CT = false, bool FIXED = false>
+// LPE = 4: four lanes per element (pair.hip.h, "four lanes per element"): 64 elements per block, both pairs of an element keep the
+// whole table and every value; the ladder steps share their products between the pairs; the first pair stores.
+template <int ALGO, bool DH, bool CT = false, bool FIXED = false, int LPE = 2>
 __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
+    static_assert(LPE == 2 || LPE == 4, "two or four lanes per element");
+    constexpr bool QUAD = LPE == 4;
+    const QuadLane ql{ QUAD && (threadIdx.x & 2) != 0 };
+    const bool writer = !ql.second;
     __shared__ __attribute__((aligned(16))) u32 lds_pair[PAIR_LDS_U32];
     PairTable tbl;
     tbl.two = reinterpret_cast<uint2*>(lds_pair) + threadIdx.x;
     tbl.one = lds_pair + PAIR_VALUES * 2 * 256 * 2 + threadIdx.x;             // behind the region of limb pairs
     const u32 odd = threadIdx.x & 1;
     const PairLane pl{ odd - 1u, 0u - odd };
-    constexpr u32 PER_BLOCK = BLOCK / 2;
+    constexpr u32 PER_BLOCK = BLOCK / LPE;
     constexpr int IN_WORDS = DH ? 8 : 20, OUT_WORDS = DH ? 8 : 20;
     const u32 n = a.n, n_round = (n + PER_BLOCK - 1) / PER_BLOCK * PER_BLOCK;
     if constexpr (FIXED) {                       // entry k, coordinate c: 12 dwords = re limbs 0..4 | im limbs 0..4 | 2 pad (load_fe2_limbs)
@@ -603,9 +609,9 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
         }
     }
 #pragma unroll 1
-    for (u32 it = blockIdx.x * PER_BLOCK + (threadIdx.x >> 1); it < n_round; it += gridDim.x * PER_BLOCK) {
-        const bool live = it < n;
-        const u32 id = a.base + (live ? it : n - 1);             // idle tail pairs redo the last element, store nothing
+    for (u32 it = blockIdx.x * PER_BLOCK + threadIdx.x / LPE; it < n_round; it += gridDim.x * PER_BLOCK) {
+        const bool live = it < n && writer;
+        const u32 id = a.base + (it < n ? it : n - 1);           // idle tail pairs redo the last element, store nothing
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
         auto half = [&](int c) {                                  // this lane's half of coordinate c of the input point: words 4c + 2 odd, + 1
@@ -633,10 +639,10 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
             if constexpr (!FIXED) pair_build_table_endo(P, tbl, pl);
             u64 v[4];
             decompose(m, v);
-            Q = pair_ladder_endo<CT>(recode(v), tbl, pl);
+            Q = pair_ladder_endo<CT, QUAD>(recode(v), tbl, pl, ql);
         } else {
             if constexpr (!FIXED) pair_build_table_windowed(P, tbl, pl);
-            Q = pair_ladder_windowed<CT>(win_reduce(m), tbl, pl);
+            Q = pair_ladder_windowed<CT, QUAD>(win_reduce(m), tbl, pl, ql);
         }
         if constexpr (DH) {
             PF<1> ax, ay;
@@ -930,7 +936,7 @@ int chain_launch_comb(unsigned grid, hipStream_t stream, const u64* scalars, con
 int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 proj_stride, u64* out, uint8_t* status, u32 n);   // k in {1, 2, 4, 8}
 // constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
-int ct_launch_pair(int algo, bool dh, bool fixed, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_pair(int algo, bool dh, bool fixed, bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
                          u32* over_scratch, u32 lanes, u32 limit);     // split_counts_kernel must already have run: see fourq_ct_chain.hip
 int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit);

@@ -241,6 +241,74 @@ FQ_DEV PProj pchi(const PProj& p, const PairLane& pl) {                         
     return r;
 }
 
+// ---- four lanes per element: the element's two pairs share the products of a formula level -----------------------------
+// Lanes 4k, 4k+1 are the FIRST pair of element k and lanes 4k+2, 4k+3 the SECOND; both pairs hold every value of the element
+// (each lane its half), so all of the pair code above runs unchanged -- twice over.  What the second pair buys: DBL and ADD are
+// levels of independent GF(p^2) products (4 squares, then 4 products; 4 products, then 3), and a level's products are taken two
+// at a time, ONE PER PAIR: the operands are chosen per pair (v_cndmask on the lane's pair bit, a public value), each pair
+// multiplies, and one quad_perm [2,3,0,1] exchange hands either result to the other pair.  981 instead of 1 454 instructions per
+// ladder step and lane: batches of at most a QUARTER generation take 0.7 of the two-lane latency (profiles/r03_quadlane.txt).
+// Same DAG, same residues (curve4q.py:138-171).
+constexpr int DPP_QSWAP = 0x4E;                         // quad_perm [2,3,0,1]
+struct QuadLane { bool second; };                       // this lane belongs to the element's second pair
+template <int A, int B> FQ_DEV PF<(A > B ? A : B)> qsel(const QuadLane& ql, const PF<A>& first, const PF<B>& second) {
+    PF<(A > B ? A : B)> r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = ql.second ? second.l[i] : first.l[i];
+    return r;
+}
+// r holds one value in the first pair and another in the second: both values to both pairs
+template <int B> FQ_DEV void qshare(const QuadLane& ql, const PF<B>& r, PF<B>& first, PF<B>& second) {
+    const PF<B> o = pdpp<DPP_QSWAP>(r);
+    first = qsel(ql, r, o); second = qsel(ql, o, r);
+}
+// DBL (curve4q.py:138-152; the signed DAG of pdbl_point).  WITH_T: also Ta*Tb of the result (= E*D, the F of R1toR3, curve4q.py:124), which
+// the addition that follows needs -- the fourth product of the second level, free on the second pair.
+template <bool WITH_T> FQ_DEV PR1 qdbl_point(const PF<1>& X, const PF<1>& Y, const PF<1>& Z, const PairLane& pl, const QuadLane& ql, PF<1>& T) {
+    const PF<1> s1 = psqr(qsel(ql, X, Y), pl);                               // X^2 | Y^2
+    const PF<1> s2 = psqr(qsel(ql, Z, padd(X, Y)), pl);                      // Z^2 | (X+Y)^2
+    PF<1> A, B, Zs, S;
+    qshare(ql, s1, A, B); qshare(ql, s2, Zs, S);
+    const PF<2> C = pdbl(Zs);
+    const PF<2> D = padd(A, B);
+    const PF<3> E = psub(S, D);
+    const PF<2> F = psub(B, A);
+    const PF<4> G = psub(C, F);
+    PR1 r;
+    const PF<1> p1 = pmul(G, qsel(ql, E, F), pl);                            // X3 = G*E | Z3 = G*F
+    qshare(ql, p1, r.X, r.Z);
+    if constexpr (WITH_T) {
+        const PF<1> p2 = pmul(D, qsel(ql, F, E), pl);                        // Y3 = D*F | T3 = D*E
+        qshare(ql, p2, r.Y, T);
+    } else {
+        r.Y = pmul(D, F, pl);
+        T = r.Y;
+    }
+    r.Ta = E; r.Tb = D;
+    return r;
+}
+// Q + (+-t) for Q = (X, Y, Z, .., ..) with T = Ta*Tb: R1toR3 (curve4q.py:119-126), the sign by masks (selectpt, curve4q.py:193-206),
+// ADD_core (curve4q.py:155-171).  The first pair takes p.D*q.D and q.F*p.F, the second p.N*q.N and q.E*p.E: with the sign, the first
+// wants (neg ? N : D) of the entry and the second (neg ? D : N) -- ONE masked select on neg ^ pair instead of the two of the pair code.
+FQ_DEV PR1 qadd_signed_entry(const PR1& Q, const PF<1>& T, const PR2& t, u32 neg, const PairLane& pl, const QuadLane& ql) {
+    asm("" : "+v"(neg) : "v"(Q.X.l[0]), "v"(Q.Y.l[0]), "v"(Q.Z.l[0]));
+    const u32 pick_n = neg ^ (ql.second ? ~0u : 0u);
+    PF<2> v1;
+#pragma unroll
+    for (int k = 0; k < 5; k++) v1.l[k] = __builtin_amdgcn_bitop3_b32(pick_n, t.N.l[k], t.D.l[k], 0xCA);
+    const PF<1> r1 = pmul(qsel(ql, psub(Q.Y, Q.X), padd(Q.X, Q.Y)), v1, pl);          // A = p.D*q.D | B = p.N*q.N
+    const PF<1> r2 = pmul(qsel(ql, pcneg(t.F, neg), t.E), qsel(ql, T, Q.Z), pl);      // C = q.F*p.F | D = q.E*p.E
+    PF<1> A, B, C, D;
+    qshare(ql, r1, A, B); qshare(ql, r2, C, D);
+    const PF<2> E = psub(B, A), F = psub(D, C), G = padd(D, C), H = padd(B, A);
+    PR1 r;
+    const PF<1> r3 = pmul(qsel(ql, E, G), qsel(ql, F, H), pl);                         // X = E*F | Y = G*H
+    qshare(ql, r3, r.X, r.Y);
+    r.Z = pmul(F, G, pl);
+    r.Ta = pwiden<3>(E); r.Tb = H;
+    return r;
+}
+
 // ---- the pair's table in LDS -----------------------------------------------------------------------------------------
 // 8 entries x 4 coordinates x 5 limbs per LANE (each lane keeps its half): 640 bytes per lane, 256 lanes = the CU's 160 KiB, so a
 // block is 128 elements and a generation 32 768.  Limb pairs (0,1), (2,3) live in a uint2 region and limb 4 in a u32 region, both
@@ -319,13 +387,19 @@ FQ_DEV void pair_build_table_endo(const PR1& P, const PairTable& tbl, const Pair
 // sign applied by masked selects behind the doubling (as add_entry in curve.hip.h).
 FQ_DEV PR1 pair_start(const PR2& t, u32 neg);
 FQ_DEV PR1 padd_signed_entry(const PR1& Q, const PR2& t, u32 neg, const PairLane& pl);
-template <bool CT> FQ_DEV PR1 pair_ladder_endo(const EndoDigits& e, const PairTable& tbl, const PairLane& pl) {
+template <bool CT, bool QUAD = false> FQ_DEV PR1 pair_ladder_endo(const EndoDigits& e, const PairTable& tbl, const PairLane& pl, const QuadLane& ql) {
     PR1 Q = pair_start(tbl.select_entry<CT>(e.top & 7), 0u);  // s[64] = 1: the entry itself
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
         const PR2 t = tbl.select_entry<CT>(endo_digit(e, i)); // read a whole doubling ahead of its use
-        Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
-        Q = padd_signed_entry(Q, t, endo_neg_mask(e, i), pl);
+        if constexpr (QUAD) {
+            PF<1> T;
+            Q = qdbl_point<true>(Q.X, Q.Y, Q.Z, pl, ql, T);
+            Q = qadd_signed_entry(Q, T, t, endo_neg_mask(e, i), pl, ql);
+        } else {
+            Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
+            Q = padd_signed_entry(Q, t, endo_neg_mask(e, i), pl);
+        }
     }
     return Q;
 }
@@ -374,16 +448,24 @@ FQ_DEV PR1 pair_start(const PR2& t, u32 neg) {
     Q.Ta = pwiden<3>(Q.X); Q.Tb = pwiden<2>(Q.Y);
     return Q;
 }
-template <bool CT> FQ_DEV PR1 pair_ladder_windowed(const WinScalar& w, const PairTable& tbl, const PairLane& pl) {     // curve4q.py:228-235
+template <bool CT, bool QUAD = false> FQ_DEV PR1 pair_ladder_windowed(const WinScalar& w, const PairTable& tbl, const PairLane& pl, const QuadLane& ql) {     // curve4q.py:228-235
     u32 code = win_top_code(w);
     PR1 Q = pair_start(tbl.select_entry<CT>(code & 7), (code >> 3) - 1u);
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
         code = win_code_from_window(win_window(w, i));
         const PR2 t = tbl.select_entry<CT>(code & 7);
+        if constexpr (QUAD) {
+            PF<1> T;
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
-        Q = padd_signed_entry(Q, t, (code >> 3) - 1u, pl);
+            for (int k = 0; k < 3; k++) Q = qdbl_point<false>(Q.X, Q.Y, Q.Z, pl, ql, T);
+            Q = qdbl_point<true>(Q.X, Q.Y, Q.Z, pl, ql, T);
+            Q = qadd_signed_entry(Q, T, t, (code >> 3) - 1u, pl, ql);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
+            Q = padd_signed_entry(Q, t, (code >> 3) - 1u, pl);
+        }
     }
     return Q;
 }

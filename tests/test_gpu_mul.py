@@ -183,17 +183,21 @@ def test_full_size_cfg5_mixed_vs_c_oracle(eng):
     assert 0.49 < flags.mean() < 0.51 and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("pair_max", ["0", None])
+@pytest.mark.parametrize("pair_max", ["one lane per element", "two at most", "four at most"])
 def test_one_lane_and_two_lane_kernels_on_small_batches_and_tails(pair_max, monkeypatch):
     """Plain variable-base MUL_endo: batches of at most half a generation, and the tail of a batch past whole generations, run two
-    lanes per element (pair.hip.h: real parts in even lanes, imaginary parts in odd lanes); FOURQ_PAIR_MAX=0 keeps everything on
-    the one-lane fused kernel.  Same R1 tuples either way: edge scalars on G and -G, ragged sizes around the 128-element block,
-    the switch at half a generation, and a tail behind one fused generation -- every output against the C oracle."""
+    lanes per element (pair.hip.h: real parts in even lanes, imaginary parts in odd lanes), those of at most a quarter generation FOUR
+    (two pairs sharing the products of every formula level); FOURQ_PAIR_MAX=0 keeps everything on the one-lane fused kernel,
+    FOURQ_QUAD_MAX=0 everything small on the two-lane kernels.  Same R1 tuples every way: edge scalars on G and -G, ragged sizes
+    around the 64- and 128-element blocks, the switches at a quarter and at half a generation, and a tail behind one fused generation
+    -- every output against the C oracle."""
     from fourq_amd import Engine
-    if pair_max is None:
-        monkeypatch.delenv("FOURQ_PAIR_MAX", raising=False)
-    else:
-        monkeypatch.setenv("FOURQ_PAIR_MAX", pair_max)
+    monkeypatch.delenv("FOURQ_PAIR_MAX", raising=False)
+    monkeypatch.delenv("FOURQ_QUAD_MAX", raising=False)
+    if pair_max == "one lane per element":
+        monkeypatch.setenv("FOURQ_PAIR_MAX", "0")
+    elif pair_max == "two at most":
+        monkeypatch.setenv("FOURQ_QUAD_MAX", "0")
     N = o.N
     edge = [0, 1, 2, N - 1, N, N + 1, 2 * N, 1 << 255, (1 << 256) - 1]
     negG = o.AffineToR1(o.GFp2.neg(o.Gx), o.Gy)
@@ -206,7 +210,7 @@ def test_one_lane_and_two_lane_kernels_on_small_batches_and_tails(pair_max, monk
         sc = seeded_scalars(61, n)
         pts = torsion_points(e, 62, n)
         want = oc.mul(oc.ENDO, sc, pts)
-        for m in (1, 2, 127, 128, 129, 255, 4097, lanes // 2, lanes // 2 + 1, lanes + 1, lanes + 300):
+        for m in (1, 2, 63, 64, 65, 127, 128, 129, 255, 4097, lanes // 4, lanes // 4 + 1, lanes // 2, lanes // 2 + 1, lanes + 1, lanes + 300):
             assert np.array_equal(e.mul_endo(sc[:m], pts[:m]), want[:m]), (pair_max, m)
         e.ct_select = True                                        # the pair-lane kernels with the lane's table scanned at every step
         for m in (1, 129, 4097, lanes + 300):

@@ -13,6 +13,17 @@ CLASSES = ["random", "zero", "ones", "same"]
 SUBJECT = ("ladder_kernel", "comb_kernel", "normalize_kernel", "prep_kernel", "pair_kernel")
 
 
+def is_ct_kernel(kname):
+    """The CT template argument: the last one of ladder_kernel<ALGO, SRC, DH, DEFER, CT> and comb_kernel<.., CT>, the third of
+    pair_kernel<ALGO, DH, CT, FIXED, LPE>; normalize_kernel has no table."""
+    if kname.startswith("normalize_kernel"):
+        return True
+    args = [a.strip() for a in kname[kname.find("<") + 1:kname.rfind(">")].split(",")]
+    if kname.startswith("pair_kernel"):
+        return len(args) > 2 and args[2] == "true"
+    return bool(args) and args[-1] == "true"
+
+
 def short(name):
     n = name.replace("void fq::(anonymous namespace)::", "").replace("fq::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
     return n.split("(")[0]
@@ -57,7 +68,7 @@ for mode in ("ct", "default"):
                 table[key][cls] = sum(vals) / len(vals)
     print("%-44s %-22s %14s %14s %14s %14s   %s" % ("kernel", "counter (mean per launch)", *CLASSES, "max spread"))
     for (kname, ctr), per in sorted(table.items()):
-        if mode == "ct" and ", true>" not in kname and not kname.startswith("normalize_kernel"):
+        if mode == "ct" and not is_ct_kernel(kname):
             continue                                   # the probe's set-up launches (default-mode kernels), not the subject
         vals = [per.get(c) for c in CLASSES]
         have = [v for v in vals if v is not None]

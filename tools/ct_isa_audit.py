@@ -83,6 +83,10 @@ ADDRESS_OPS = ("v_add_u32", "v_add_co_u32", "v_addc_co_u32", "v_add_nc_u32", "v_
                "v_mov_b32", "v_mov_b64", "v_or_b32", "v_lshlrev_b32", "v_lshlrev_b64", "v_accvgpr_read", "v_accvgpr_write", "v_mad_u32_u24", "v_mul_u32_u24",
                "v_and_b32", "v_or3_b32", "v_lshl_or_b32", "v_and_or_b32")
 LADDER_MADS = (1300, 1200, 650)      # static multiply-adds of one ladder step (DBL + ADD; 4 DBL in an inner loop + ADD) / one comb column / a pair-lane step
+# four lanes per element (pair_kernel<..., 4>): a MUL_endo step is 350 multiply-adds, a MUL_windowed step 500 (the loop of three doublings
+# counted once) -- and only the ladder steps exchange between an element's two pairs (quad_perm:[2,3,0,1]); the table-building loops of the
+# same kernels, which also hold 500, are the two-lane code and do not
+QUAD_MADS = (350, 500)
 
 
 def defs_of(ins):
@@ -189,7 +193,12 @@ def audit_kernel(name, body):
 
     def mads_of(lo, hi):
         return sum(1 for x in instrs[lo:hi + 1] if x.startswith(("v_mad_u64_u32", "v_mad_i64_i32")))
-    ladder = [(lo, hi) for lo, hi in loops if mads_of(lo, hi) in LADDER_MADS]
+    if "pair_kernel" in name and "ELi4EEE" in name:
+        def shares(lo, hi):
+            return any("quad_perm:[2,3,0,1]" in x for x in instrs[lo:hi + 1])
+        ladder = [(lo, hi) for lo, hi in loops if mads_of(lo, hi) in QUAD_MADS and shares(lo, hi)]
+    else:
+        ladder = [(lo, hi) for lo, hi in loops if mads_of(lo, hi) in LADDER_MADS]
     # the ladder-step / comb-column loops are the INNERMOST loops with a whole step's multiply-adds (the element loop around
     # them, which for a bare MUL kernel has the same count, is public control flow: it indexes by element number)
     ladder = [(lo, hi) for lo, hi in ladder if not any((l2, h2) != (lo, hi) and lo <= l2 and h2 <= hi for l2, h2 in ladder)]

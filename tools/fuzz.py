@@ -28,7 +28,8 @@ def scalars(n):
 
 
 def pick_n(lanes):
-    edges = [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, lanes - 1, lanes, lanes + 1, 2 * lanes - 1, 2 * lanes, 2 * lanes + 1, 4 * lanes + 3]
+    edges = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 4095, 4096, 4097, lanes // 4 - 1, lanes // 4, lanes // 4 + 1, lanes // 2, lanes // 2 + 1,
+             lanes - 1, lanes, lanes + 1, lanes + 64, lanes + lanes // 4, lanes + lanes // 4 + 1, 2 * lanes - 1, 2 * lanes, 2 * lanes + 1, 4 * lanes + 3]
     return rng.choice(edges) if rng.random() < 0.5 else rng.randrange(1, 3 * lanes)
 
 
@@ -52,7 +53,9 @@ while time.time() < t_end:
         knobs["FOURQ_MIXED_QUEUE"] = rng.choice(["0", "1"])          # round 3: the persistent work-queue kernel forced on / off
     if rng.random() < 0.3:
         knobs["FOURQ_PAIR_MAX"] = rng.choice(["0", "100", "5000"])     # round 3: the two-lanes-per-element kernel off / for tiny tails only
-    for k in ("FOURQ_PAIR_MAX", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
+    if rng.random() < 0.3:
+        knobs["FOURQ_QUAD_MAX"] = rng.choice(["0", "64", "1000"])      # the four-lanes-per-element kernels off / for tiny batches and tails only
+    for k in ("FOURQ_PAIR_MAX", "FOURQ_QUAD_MAX", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     with Engine(0) as eng:
