@@ -630,18 +630,18 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
         if constexpr (DH) {
             const PF<1> x = half(0), y = half(1);
             if (!pair_point_on_curve(x, y, pl)) st = FOURQ_DH_NOT_ON_CURVE;      // keep going branch-free; masked at the end
-            if constexpr (!FIXED) P = pair_clear_cofactor_392(x, y, pl);
+            if constexpr (!FIXED) P = pair_clear_cofactor_392<QUAD>(x, y, pl, ql);
         } else if constexpr (!FIXED) {
             P.X = half(0); P.Y = half(1); P.Z = half(2); P.Ta = pwiden<3>(half(3)); P.Tb = pwiden<2>(half(4));
         }
         PR1 Q;
         if constexpr (ALGO == ENDO) {
-            if constexpr (!FIXED) pair_build_table_endo(P, tbl, pl);
+            if constexpr (!FIXED) pair_build_table_endo<QUAD>(P, tbl, pl, ql);
             u64 v[4];
             decompose(m, v);
             Q = pair_ladder_endo<CT, QUAD>(recode(v), tbl, pl, ql);
         } else {
-            if constexpr (!FIXED) pair_build_table_windowed(P, tbl, pl);
+            if constexpr (!FIXED) pair_build_table_windowed<QUAD>(P, tbl, pl, ql);
             Q = pair_ladder_windowed<CT, QUAD>(win_reduce(m), tbl, pl, ql);
         }
         if constexpr (DH) {

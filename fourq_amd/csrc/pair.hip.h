@@ -246,7 +246,7 @@ FQ_DEV PProj pchi(const PProj& p, const PairLane& pl) {                         
 // (each lane its half), so all of the pair code above runs unchanged -- twice over.  What the second pair buys: DBL and ADD are
 // levels of independent GF(p^2) products (4 squares, then 4 products; 4 products, then 3), and a level's products are taken two
 // at a time, ONE PER PAIR: the operands are chosen per pair (v_cndmask on the lane's pair bit, a public value), each pair
-// multiplies, and one quad_perm [2,3,0,1] exchange hands either result to the other pair.  981 instead of 1 454 instructions per
+// multiplies, and one quad_perm [2,3,0,1] exchange hands either result to the other pair.  978 instead of 1 454 instructions per
 // ladder step and lane: batches of at most a QUARTER generation take 0.7 of the two-lane latency (profiles/r03_quadlane.txt).
 // Same DAG, same residues (curve4q.py:138-171).
 constexpr int DPP_QSWAP = 0x4E;                         // quad_perm [2,3,0,1]
@@ -360,7 +360,7 @@ struct PairTable {
 // T[k] = P + k0*phi(P) + k1*psi(P) + k2*psi(phi(P)), built in the reference's order (curve4q.py:385-403): the structure of
 // build_table_endo (kernels.hip.h), with the three endomorphism evaluations sharing one instance of tau, chi / upsilon, tau_dual.
 // The working points stay in registers (a half point is 25 of them); the bases T[0..3] are read back from LDS.
-FQ_DEV void pair_build_table_endo(const PR1& P, const PairTable& tbl, const PairLane& pl) {
+template <bool QUAD = false> FQ_DEV void pair_build_table_endo(const PR1& P, const PairTable& tbl, const PairLane& pl, const QuadLane& ql) {
     tbl.put_entry(0, pr1_to_r2(P, pl));
     PF<1> X = P.X, Y = P.Y, Z = P.Z;               // step 0: P, step 1: tau(P) (shared by phi and psi), step 2: phi(P)
     PF<1> QX = P.X, QY = P.Y, QZ = P.Z;            // phi(P), produced by step 0
@@ -379,7 +379,10 @@ FQ_DEV void pair_build_table_endo(const PR1& P, const PairTable& tbl, const Pair
         const PR3 V3 = pr1_to_r3(V, pl);
         const int half = 1 << step;
 #pragma unroll 1
-        for (int m = 0; m < half; m++) tbl.put_entry(half + m, pr1_to_r2(padd_core(V3, tbl.get_entry((u32)m), pl), pl));
+        for (int m = 0; m < half; m++) {
+            if constexpr (QUAD) tbl.put_entry(half + m, pr1_to_r2(qadd_signed_entry(V, V3.F, tbl.get_entry((u32)m), 0u, pl, ql), pl));   // the addition's products shared by the two pairs
+            else tbl.put_entry(half + m, pr1_to_r2(padd_core(V3, tbl.get_entry((u32)m), pl), pl));
+        }
     }
 }
 
@@ -405,13 +408,15 @@ template <bool CT, bool QUAD = false> FQ_DEV PR1 pair_ladder_endo(const EndoDigi
 }
 
 // T[0] = R1toR2(P); T[i] = R1toR2(ADD(DBL(P), T[i-1]))                                      curve4q.py:179-185
-FQ_DEV void pair_build_table_windowed(const PR1& P, const PairTable& tbl, const PairLane& pl) {
-    const PR3 twoP = pr1_to_r3(pdbl_point(P.X, P.Y, P.Z, pl), pl);
+template <bool QUAD = false> FQ_DEV void pair_build_table_windowed(const PR1& P, const PairTable& tbl, const PairLane& pl, const QuadLane& ql) {
+    const PR1 twoP1 = pdbl_point(P.X, P.Y, P.Z, pl);
+    const PR3 twoP = pr1_to_r3(twoP1, pl);
     PR2 t = pr1_to_r2(P, pl);
     tbl.put_entry(0, t);
 #pragma unroll 1
     for (int i = 1; i < 8; i++) {
-        t = pr1_to_r2(padd_core(twoP, t, pl), pl);
+        if constexpr (QUAD) t = pr1_to_r2(qadd_signed_entry(twoP1, twoP.F, t, 0u, pl, ql), pl);
+        else t = pr1_to_r2(padd_core(twoP, t, pl), pl);
         tbl.put_entry(i, t);
     }
 }
@@ -482,11 +487,24 @@ FQ_DEV u32 pair_point_on_curve(const PF<1>& x, const PF<1>& y, const PairLane& p
     pair_canon(lhs, a0, a1); pair_canon(rhs, b0, b1);
     return pair_both((a0 == b0 && a1 == b1) ? 1u : 0u);
 }
-FQ_DEV PR1 pair_clear_cofactor_392(const PF<1>& x, const PF<1>& y, const PairLane& pl) {            // curve4q.py:450-455
+template <bool QUAD = false> FQ_DEV PR1 pair_clear_cofactor_392(const PF<1>& x, const PF<1>& y, const PairLane& pl, const QuadLane& ql) {   // curve4q.py:450-455
     PR1 p0;
     p0.X = x; p0.Y = y; p0.Z = pair_one(pl); p0.Ta = pwiden<3>(x); p0.Tb = pwiden<2>(y);
     const PR2 t0 = pr1_to_r2(p0, pl);
-    PR1 q = padd_core(pr1_to_r3(pdbl_point(p0.X, p0.Y, p0.Z, pl), pl), t0, pl);       // 3P
+    PR1 q;
+    if constexpr (QUAD) {                                                                 // the same chain on the shared-product steps
+        PF<1> T;
+        q = qdbl_point<true>(p0.X, p0.Y, p0.Z, pl, ql, T);
+        q = qadd_signed_entry(q, T, t0, 0u, pl, ql);                                      // 3P
+#pragma unroll 1
+        for (int i = 0; i < 3; i++) q = qdbl_point<false>(q.X, q.Y, q.Z, pl, ql, T);
+        q = qdbl_point<true>(q.X, q.Y, q.Z, pl, ql, T);                                   // 48P
+        q = qadd_signed_entry(q, T, t0, 0u, pl, ql);                                      // 49P
+#pragma unroll 1
+        for (int i = 0; i < 3; i++) q = qdbl_point<false>(q.X, q.Y, q.Z, pl, ql, T);      // 392P
+        return q;
+    }
+    q = padd_core(pr1_to_r3(pdbl_point(p0.X, p0.Y, p0.Z, pl), pl), t0, pl);           // 3P
 #pragma unroll 1
     for (int i = 0; i < 4; i++) q = pdbl_point(q.X, q.Y, q.Z, pl);                    // 48P
     q = padd_core(pr1_to_r3(q, pl), t0, pl);                                          // 49P

@@ -83,10 +83,10 @@ ADDRESS_OPS = ("v_add_u32", "v_add_co_u32", "v_addc_co_u32", "v_add_nc_u32", "v_
                "v_mov_b32", "v_mov_b64", "v_or_b32", "v_lshlrev_b32", "v_lshlrev_b64", "v_accvgpr_read", "v_accvgpr_write", "v_mad_u32_u24", "v_mul_u32_u24",
                "v_and_b32", "v_or3_b32", "v_lshl_or_b32", "v_and_or_b32")
 LADDER_MADS = (1300, 1200, 650)      # static multiply-adds of one ladder step (DBL + ADD; 4 DBL in an inner loop + ADD) / one comb column / a pair-lane step
-# four lanes per element (pair_kernel<..., 4>): a MUL_endo step is 350 multiply-adds, a MUL_windowed step 500 (the loop of three doublings
-# counted once) -- and only the ladder steps exchange between an element's two pairs (quad_perm:[2,3,0,1]); the table-building loops of the
-# same kernels, which also hold 500, are the two-lane code and do not
-QUAD_MADS = (350, 500)
+# four lanes per element (pair_kernel<..., 4>): a ladder step is known by its multiply-adds AND its exchanges between the element's two pairs
+# (v_mov_b32_dpp quad_perm:[2,3,0,1], five per shared result): MUL_endo 350 / 35 (7 results), MUL_windowed 500 / 50 (the loop of three doublings
+# counted once: 3 + 4 + 3 results).  The table-building loops of the same kernels share 3 results per addition (300 / 15).
+QUAD_STEP = ((350, 35), (500, 50))
 
 
 def defs_of(ins):
@@ -195,8 +195,8 @@ def audit_kernel(name, body):
         return sum(1 for x in instrs[lo:hi + 1] if x.startswith(("v_mad_u64_u32", "v_mad_i64_i32")))
     if "pair_kernel" in name and "ELi4EEE" in name:
         def shares(lo, hi):
-            return any("quad_perm:[2,3,0,1]" in x for x in instrs[lo:hi + 1])
-        ladder = [(lo, hi) for lo, hi in loops if mads_of(lo, hi) in QUAD_MADS and shares(lo, hi)]
+            return sum(1 for x in instrs[lo:hi + 1] if "quad_perm:[2,3,0,1]" in x)
+        ladder = [(lo, hi) for lo, hi in loops if (mads_of(lo, hi), shares(lo, hi)) in QUAD_STEP]
     else:
         ladder = [(lo, hi) for lo, hi in loops if mads_of(lo, hi) in LADDER_MADS]
     # the ladder-step / comb-column loops are the INNERMOST loops with a whole step's multiply-adds (the element loop around

@@ -17,6 +17,8 @@ for g in 2 4; do
 done
 python3 tools/single_call_probe.py > gpurun_out/r03f/single_call.txt 2>&1 || { tail -20 gpurun_out/r03f/single_call.txt; exit 1; }
 cat gpurun_out/r03f/single_call.txt
+python3 tools/quad_probe.py > gpurun_out/r03f/quad_probe.txt 2> gpurun_out/r03f/quad_probe.err || { tail -20 gpurun_out/r03f/quad_probe.err; exit 1; }
+cat gpurun_out/r03f/quad_probe.txt
 python3 -c "
 import json
 for f in ('bench','bench_driver_args','rehearse_gpus2','rehearse_gpus4'):
