@@ -6,4 +6,4 @@ python3 tools/fuzz.py 240 > gpurun_out/r03f/fuzz.txt 2>&1 || { tail -30 gpurun_o
 tail -25 gpurun_out/r03f/fuzz.txt
 python3 tools/soak.py > gpurun_out/r03f/soak.txt 2>&1 || { tail -30 gpurun_out/r03f/soak.txt; exit 1; }
 FOURQ_CT_SELECT=1 python3 tools/soak.py > gpurun_out/r03f/soak_ct.txt 2>&1 || { tail -30 gpurun_out/r03f/soak_ct.txt; exit 1; }
-tail -4 gpurun_out/r03f/soak.txt gpurun_out/r03f/soak_ct.txt
+tail -n 3 gpurun_out/r03f/soak.txt; tail -n 3 gpurun_out/r03f/soak_ct.txt
