@@ -694,31 +694,44 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     const int slots = chunks < (size_t)PIPE_SLOTS ? (int)chunks : PIPE_SLOTS;
     int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
     if (rc) return rc;
-    // A single small chunk (the reference-shaped call is a batch of one): copies and kernels in order on the context's own stream.
-    // Nothing can overlap, so the three-stream choreography below only adds its cross-stream event hops to the call's latency.
-    if (chunks == 1 && slot <= (1u << 20)) {
-        char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
-        for (int i = 0; i < n_in; i++) {
-            din[i] = c->pipe_dev + off_in[i];
-            HIP_TRY(c, hipMemcpyAsync(din[i], in[i].src, n * in[i].stride, hipMemcpyHostToDevice, c->stream));
-            st.h2d_bytes += n * in[i].stride;
-        }
-        for (int i = 0; i < n_out; i++) dout[i] = c->pipe_dev + off_out[i];
-        if ((rc = launch(din, dout, n))) return rc;
-        for (int i = 0; i < n_out; i++) {
-            HIP_TRY(c, hipMemcpyAsync(out[i].dst, dout[i], n * out[i].stride, hipMemcpyDeviceToHost, c->stream));
-            st.d2h_bytes += n * out[i].stride;
-        }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->host_stats = st;                    // copy durations are not timed on this path (h2d_ms = d2h_ms = 0)
-        return FOURQ_OK;
-    }
-    if (bounce && (rc = grow(c, &c->pipe_pin, &c->pipe_pin_bytes, slot * slots, true))) return rc;
     while (c->ticks.size() < 4 * (size_t)PIPE_SLOTS) {
         hipEvent_t e;
         HIP_TRY(c, hipEventCreate(&e));
         c->ticks.push_back(e);
     }
+    // A single chunk (down to the reference-shaped call, a batch of one): copies and kernels in order on the context's own stream.
+    // Nothing can overlap, so the three-stream choreography below would only add its cross-stream event hops (50 us) to the call.
+    // Calls of at most 1 MiB skip even the four timing events (a few us of a 0.19 ms call): their copy durations read 0.
+    if (chunks == 1) {
+        const bool timed = slot > (1u << 20);
+        char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[0], c->stream));
+        for (int i = 0; i < n_in; i++) {
+            din[i] = c->pipe_dev + off_in[i];
+            HIP_TRY(c, hipMemcpyAsync(din[i], in[i].src, n * in[i].stride, hipMemcpyHostToDevice, c->stream));
+            st.h2d_bytes += n * in[i].stride;
+        }
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[1], c->stream));
+        for (int i = 0; i < n_out; i++) dout[i] = c->pipe_dev + off_out[i];
+        if ((rc = launch(din, dout, n))) return rc;
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[2], c->stream));
+        for (int i = 0; i < n_out; i++) {
+            HIP_TRY(c, hipMemcpyAsync(out[i].dst, dout[i], n * out[i].stride, hipMemcpyDeviceToHost, c->stream));
+            st.d2h_bytes += n * out[i].stride;
+        }
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[3], c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (timed) {
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[0], c->ticks[1]));
+            st.h2d_ms = ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[2], c->ticks[3]));
+            st.d2h_ms = ms;
+        }
+        c->host_stats = st;
+        return FOURQ_OK;
+    }
+    if (bounce && (rc = grow(c, &c->pipe_pin, &c->pipe_pin_bytes, slot * slots, true))) return rc;
 
     auto drain = [&](size_t k) -> int {          // chunk k has left the device: hand a pageable caller its bytes
         const int b = (int)(k % slots);

@@ -115,8 +115,8 @@ int fourq_host_alloc(fourq_ctx *ctx, size_t bytes, void **out);
 int fourq_host_free(fourq_ctx *ctx, void *ptr);
 /* transfer statistics of the context's last host-pointer batch call */
 typedef struct fourq_host_stats {
-    double h2d_ms, d2h_ms;          /* summed durations of the chunk copies, HIP events on the copy streams; 0 for a call of
-                                     * one chunk of at most 1 MiB, which runs in order on the context's stream untimed */
+    double h2d_ms, d2h_ms;          /* summed durations of the chunk copies (HIP events); 0 for a call of at most 1 MiB, which
+                                     * runs in order on the context's stream untimed */
     uint64_t h2d_bytes, d2h_bytes;
     uint32_t chunks;
     int pinned_in, pinned_out;      /* 1: every input / output array was pinned (no bounce copy) */

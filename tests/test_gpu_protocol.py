@@ -187,8 +187,9 @@ def test_host_pipeline_chunks_and_pinned_memory(eng, pinned):
 
 @pytest.mark.parametrize("pinned", [False, True])
 def test_small_host_call_runs_in_order_on_the_context_stream(eng, pinned):
-    """A call of one chunk of at most 1 MiB (the reference-shaped call is a batch of one) skips the three-stream pipeline:
-    same results, byte counts reported, copy durations untimed (0); one element more than the limit takes the pipeline."""
+    """A call of one chunk runs in order on the context's stream instead of the three-stream pipeline; at most 1 MiB (the
+    reference-shaped call is a batch of one) it is not even timed: same results, byte counts reported, copy durations 0; one
+    element more than the limit and the durations are there."""
     put = (lambda x: eng.host_array(x)) if pinned else (lambda x: x)
     te = oc.table(oc.ENDO, codec.pack_point(G1))
     for n in (1, 7, 2977, 2978):                               # 2977 x (32 + 160 + 160) B in 256-byte-aligned arrays: just under 1 MiB; 2978: just over
