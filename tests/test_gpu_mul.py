@@ -230,18 +230,22 @@ def test_one_lane_and_two_lane_kernels_on_small_batches_and_tails(pair_max, monk
         # the other variable-base entry points take the same route: MUL_windowed, DH_endo / DH_windowed with both rejections
         k = 5000
         want_w = oc.mul(oc.WINDOWED, sc[:k], pts[:k])
-        for m in (1, 129, k):
-            assert np.array_equal(e.mul_windowed(sc[:m], pts[:m]), want_w[:m]), (pair_max, m)
         aff = e.prim("PT_R1TOAFFINE", pts[:k]).copy()
         aff[7, 0] ^= 1                                            # not on the curve
         P392 = codec.pack_point(_kat_p392())
         aff[11] = P392                                            # order divides 392: the neutral point after cofactor clearing
-        for algo, fn in ((oc.ENDO, e.dh_endo), (oc.WINDOWED, e.dh_windowed)):
-            want_d, want_st = oc.dh(algo, sc[:k], aff)
-            for m in (1, 12, 129, k):
-                got_d, got_st = fn(sc[:m], aff[:m])
-                assert np.array_equal(got_st, want_st[:m]) and np.array_equal(got_d, want_d[:m]), (pair_max, algo, m)
-            assert want_st[7] == 1 and want_st[11] == 2
+        want_dh = {algo: oc.dh(algo, sc[:k], aff) for algo in (oc.ENDO, oc.WINDOWED)}
+        for ct in (False, True):                                  # both selection modes of every variable-base kernel of the route
+            e.ct_select = ct
+            for m in (1, 129, k):
+                assert np.array_equal(e.mul_windowed(sc[:m], pts[:m]), want_w[:m]), (pair_max, ct, m)
+            for algo, fn in ((oc.ENDO, e.dh_endo), (oc.WINDOWED, e.dh_windowed)):
+                want_d, want_st = want_dh[algo]
+                for m in (1, 12, 129, k):
+                    got_d, got_st = fn(sc[:m], aff[:m])
+                    assert np.array_equal(got_st, want_st[:m]) and np.array_equal(got_d, want_d[:m]), (pair_max, ct, algo, m)
+                assert want_st[7] == 1 and want_st[11] == 2
+        e.ct_select = False
         # fixed base: the caller's table copied into the lanes' LDS rows (pair_kernel<..., FIXED>) or staged once per block (LDS ladders)
         te, tw = e.table_endo(codec.pack_point(G1)), e.table_windowed(codec.pack_point(G1))
         for ct in (False, True):
