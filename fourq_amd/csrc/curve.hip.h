@@ -549,11 +549,48 @@ template <typename P> FQ_DEV R1 affine_table_start(const P* entry, u32 neg_mask)
 //   ScanMem    the table in LDS (all lanes read the same addresses: broadcasts) or in global memory
 //   ScanSplit  a per-lane table: N, D in registers, E, F in the lane's LDS rows (fused variable-base kernels: no global
 //              memory traffic in the ladder)
-FQ_DEV u32 eq_mask(u32 a, u32 b) { return 0u - (u32)(a == b); }
-template <int N> FQ_DEV void masked_or(u32 acc[N], const u32 v[N], u32 m) {
+// One of 2^LOG values by a binary TREE of masked selects: neighbours by bit 0 of the digit, neighbouring winners by bit 1, and so on --
+// ENTRIES - 1 selects per limb (v_bitop3_b32, truth table 0xCA) where a scan with one equality mask per entry takes ENTRIES
+// compares and ENTRIES masked ORs.  The bit masks live in vector registers and are opaque to hipcc: from a visible `0 - (a == b)`
+// it makes v_cmp / v_cndmask pairs, whose SGPR hazards cost the constant-time ladder step 80 s_nop besides (141 against 60).
+// Round 3: 486 -> 280 selection instructions per fused step, constant-time cfg2 x1.29 -> see DESIGN.md section 10.
+template <int LOG> struct DigitBits {
+    u32 m[LOG];                                    // m[j] = ~0 where bit j of the digit is set
+    FQ_DEV explicit DigitBits(u32 digit) {
 #pragma unroll
-    for (int i = 0; i < N; i++) acc[i] |= v[i] & m;
+        for (int j = 0; j < LOG; j++) { u32 x = 0u - ((digit >> j) & 1u); asm("" : "+v"(x)); m[j] = x; }
+    }
+};
+constexpr int log2_of(int n) { return n <= 1 ? 0 : 1 + log2_of(n / 2); }
+template <int N> FQ_DEV void pick(u32 r[N], u32 mask, const u32 hi[N], const u32 lo[N]) {      // mask ? hi : lo, limb by limb
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = __builtin_amdgcn_bitop3_b32(mask, hi[i], lo[i], 0xCA);
 }
+// The entries arrive in pairs (2P, 2P + 1), P = 0, 1, ...: the winner of a finished subtree waits in pend[] for its sibling, so at most
+// LOG - 1 partial results are alive whatever ENTRIES is.  After the last pair `out` holds entry `digit`.
+template <int N, int LOG> struct SelectTree {
+    u32 pend[LOG > 1 ? LOG - 1 : 1][N];
+    template <int P> FQ_DEV void feed(const DigitBits<LOG>& b, const u32 e0[N], const u32 e1[N], u32 out[N]) {
+        u32 cur[N];
+        pick<N>(cur, b.m[0], e1, e0);
+        constexpr int UP = trailing_ones(P);       // subtrees this pair completes
+#pragma unroll
+        for (int j = 0; j < UP && j < LOG - 1; j++) {
+            u32 nxt[N];
+            pick<N>(nxt, b.m[j + 1], cur, pend[j]);
+#pragma unroll
+            for (int i = 0; i < N; i++) cur[i] = nxt[i];
+        }
+        if constexpr (UP >= LOG - 1) {
+#pragma unroll
+            for (int i = 0; i < N; i++) out[i] = cur[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; i++) pend[UP][i] = cur[i];
+        }
+    }
+    static constexpr int trailing_ones(int p) { return (p & 1) ? 1 + trailing_ones(p >> 1) : 0; }
+};
 FQ_DEV Fe2<1> fe2_from_limbs(const u32 w[10]) {
     Fe2<1> r;
 #pragma unroll
@@ -573,21 +610,23 @@ template <int ENTRIES, typename TP> struct ScanMem {
     int stride;                                    // dwords between entries; coordinates are COORD_U32 apart
     // Two entries per round, rounds fenced: left alone the scheduler hoists all 3 * ENTRIES loads ahead of the masking
     // and the 128-VGPR kernels spill (measured: 1.3 KB of scratch per lane).
-    FQ_DEV Fe2<1> coord(u32 digit, int c) const {  // coordinate c of entry `digit`
-        static_assert(ENTRIES % 2 == 0, "entries are scanned in pairs");
-        u32 acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int k = 0; k < ENTRIES; k += 2) {
-            const uint4* q0 = reinterpret_cast<const uint4*>(tbl + k * stride + c * COORD_U32);
-            const uint4* q1 = reinterpret_cast<const uint4*>(tbl + (k + 1) * stride + c * COORD_U32);
-            const uint4 a0 = q0[0], b0 = q0[1], d0 = q0[2], a1 = q1[0], b1 = q1[1], d1 = q1[2];
-            const u32 v0[10] = { a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x, d0.y };
-            const u32 v1[10] = { a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w, d1.x, d1.y };
-            masked_or<10>(acc, v0, eq_mask(digit, (u32)k));
-            masked_or<10>(acc, v1, eq_mask(digit, (u32)k + 1));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        return fe2_from_limbs(acc);
+    template <int P, int LOG> FQ_DEV void pair(const DigitBits<LOG>& bits, SelectTree<10, LOG>& tree, int c, u32 out[10]) const {
+        const uint4* q0 = reinterpret_cast<const uint4*>(tbl + (2 * P) * stride + c * COORD_U32);
+        const uint4* q1 = reinterpret_cast<const uint4*>(tbl + (2 * P + 1) * stride + c * COORD_U32);
+        const uint4 a0 = q0[0], b0 = q0[1], d0 = q0[2], a1 = q1[0], b1 = q1[1], d1 = q1[2];
+        const u32 v0[10] = { a0.x, a0.y, a0.z, a0.w, b0.x, b0.y, b0.z, b0.w, d0.x, d0.y };
+        const u32 v1[10] = { a1.x, a1.y, a1.z, a1.w, b1.x, b1.y, b1.z, b1.w, d1.x, d1.y };
+        tree.template feed<P>(bits, v0, v1, out);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (2 * P + 2 < ENTRIES) pair<P + 1>(bits, tree, c, out);
+    }
+    static_assert(ENTRIES >= 2 && (ENTRIES & (ENTRIES - 1)) == 0, "a power of two of entries, scanned in pairs");
+    using Bits = DigitBits<log2_of(ENTRIES)>;      // the digit's bit masks: formed once per step, used for every coordinate
+    FQ_DEV Fe2<1> coord(const Bits& bits, int c) const {           // coordinate c of the entry the bits stand for
+        SelectTree<10, log2_of(ENTRIES)> tree;
+        u32 out[10];
+        pair<0>(bits, tree, c, out);
+        return fe2_from_limbs(out);
     }
 };
 // The fused constant-time kernels: N and D of the lane's eight entries in registers (loaded once from the HBM slot), E and F
@@ -607,27 +646,29 @@ template <typename EFT> struct ScanSplit {
             }
         }
     }
-    FQ_DEV Fe2<1> coord(u32 digit, int c) const {
-        u32 acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    template <int P> FQ_DEV void pair(const DigitBits<3>& bits, SelectTree<10, 3>& tree, int c, u32 out[10]) const {
         if (c < 2) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) masked_or<10>(acc, &nd[k][c * 10], eq_mask(digit, (u32)k));
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k += 2) {                       // two entries per round, as ScanMem
-                const Fe2<1> v0 = ef.get((u32)k, c - 2), v1 = ef.get((u32)k + 1, c - 2);
-                const u32 w0[10] = { v0.re.l[0], v0.re.l[1], v0.re.l[2], v0.re.l[3], v0.re.l[4], v0.im.l[0], v0.im.l[1], v0.im.l[2], v0.im.l[3], v0.im.l[4] };
-                const u32 w1[10] = { v1.re.l[0], v1.re.l[1], v1.re.l[2], v1.re.l[3], v1.re.l[4], v1.im.l[0], v1.im.l[1], v1.im.l[2], v1.im.l[3], v1.im.l[4] };
-                masked_or<10>(acc, w0, eq_mask(digit, (u32)k));
-                masked_or<10>(acc, w1, eq_mask(digit, (u32)k + 1));
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            tree.template feed<P>(bits, &nd[2 * P][c * 10], &nd[2 * P + 1][c * 10], out);
+        } else {                                                   // two entries per round, as ScanMem
+            const Fe2<1> v0 = ef.get((u32)(2 * P), c - 2), v1 = ef.get((u32)(2 * P + 1), c - 2);
+            const u32 w0[10] = { v0.re.l[0], v0.re.l[1], v0.re.l[2], v0.re.l[3], v0.re.l[4], v0.im.l[0], v0.im.l[1], v0.im.l[2], v0.im.l[3], v0.im.l[4] };
+            const u32 w1[10] = { v1.re.l[0], v1.re.l[1], v1.re.l[2], v1.re.l[3], v1.re.l[4], v1.im.l[0], v1.im.l[1], v1.im.l[2], v1.im.l[3], v1.im.l[4] };
+            tree.template feed<P>(bits, w0, w1, out);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        return fe2_from_limbs(acc);
+        if constexpr (P < 3) pair<P + 1>(bits, tree, c, out);
+    }
+    using Bits = DigitBits<3>;
+    FQ_DEV Fe2<1> coord(const Bits& bits, int c) const {
+        SelectTree<10, 3> tree;
+        u32 out[10];
+        pair<0>(bits, tree, c, out);
+        return fe2_from_limbs(out);
     }
 };
 // Q + (+-T[digit]), every entry read: the constant-time form of add_table
-template <int CH, typename SRC> FQ_DEV R1 add_scan(const R1& q, const SRC& src, u32 digit, u32 neg_mask) {
+template <int CH, typename SRC> FQ_DEV R1 add_scan(const R1& q, const SRC& src, u32 digit_value, u32 neg_mask) {
+    const typename SRC::Bits digit(digit_value);
     Fe2<1> T = fe2_mulx<CH>(q.Ta, q.Tb);
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
@@ -649,7 +690,8 @@ template <int CH, typename SRC> FQ_DEV R1 add_scan(const R1& q, const SRC& src, 
     r.Tb = H;
     return r;
 }
-template <typename SRC> FQ_DEV Proj<1, 1, 1> start_scan(const SRC& src, u32 digit, u32 neg_mask) {
+template <typename SRC> FQ_DEV Proj<1, 1, 1> start_scan(const SRC& src, u32 digit_value, u32 neg_mask) {
+    const typename SRC::Bits digit(digit_value);
     Fe2<1> N = src.coord(digit, 0), D = src.coord(digit, 1);
     fe2_cswap(N, D, neg_mask);
     Proj<1, 1, 1> r;
@@ -659,7 +701,8 @@ template <typename SRC> FQ_DEV Proj<1, 1, 1> start_scan(const SRC& src, u32 digi
     return r;
 }
 // the comb's mixed addition and starting point with every one of the block's entries read (3 coordinates each)
-template <int CH, typename SRC> FQ_DEV R1 add_affine_scan(const R1& q, const SRC& src, u32 idx, u32 neg_mask) {
+template <int CH, typename SRC> FQ_DEV R1 add_affine_scan(const R1& q, const SRC& src, u32 idx_value, u32 neg_mask) {
+    const typename SRC::Bits idx(idx_value);
     Fe2<4> Ta = q.Ta;
     Fe2<2> Tb = q.Tb;
     if constexpr (CH == 2) { fe2_here(Ta); fe2_here(Tb); }      // as in add_affine_table: keeps the 90 products single instructions
@@ -690,7 +733,8 @@ template <int CH, typename SRC> FQ_DEV R1 add_affine_scan(const R1& q, const SRC
     r.Tb = H;
     return r;
 }
-template <typename SRC> FQ_DEV R1 affine_scan_start(const SRC& src, u32 idx, u32 neg_mask) {
+template <typename SRC> FQ_DEV R1 affine_scan_start(const SRC& src, u32 idx_value, u32 neg_mask) {
+    const typename SRC::Bits idx(idx_value);
     Fe2<1> N = src.coord(idx, 0), D = src.coord(idx, 1);
     fe2_cswap(N, D, neg_mask);
     R1 r;

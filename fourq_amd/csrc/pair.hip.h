@@ -337,21 +337,26 @@ struct PairTable {
     }
     // constant-time selection (curve.hip.h, "constant-time selection"): EVERY entry is read -- the lane's LDS addresses depend on the
     // lane and the entry number, never on the digit -- and the wanted one kept by masks derived arithmetically from the digit
-    FQ_DEV PR2 scan_entry(u32 digit) const {
-        u32 acc[20];
+    template <int P> FQ_DEV void scan_pair(const DigitBits<3>& bits, SelectTree<20, 3>& tree, u32 out[20]) const {
+        const PR2 t0 = get_entry((u32)(2 * P)), t1 = get_entry((u32)(2 * P + 1));
+        u32 v0[20], v1[20];
 #pragma unroll
-        for (int i = 0; i < 20; i++) acc[i] = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const PR2 t = get_entry((u32)k);
-            const u32 m = eq_mask(digit, (u32)k);
-#pragma unroll
-            for (int i = 0; i < 5; i++) { acc[i] |= t.N.l[i] & m; acc[5 + i] |= t.D.l[i] & m; acc[10 + i] |= t.E.l[i] & m; acc[15 + i] |= t.F.l[i] & m; }
-            if (k & 1) __builtin_amdgcn_sched_barrier(0);      // two entries per round: left alone the scheduler hoists all 96 reads ahead of the masking
+        for (int i = 0; i < 5; i++) {
+            v0[i] = t0.N.l[i]; v0[5 + i] = t0.D.l[i]; v0[10 + i] = t0.E.l[i]; v0[15 + i] = t0.F.l[i];
+            v1[i] = t1.N.l[i]; v1[5 + i] = t1.D.l[i]; v1[10 + i] = t1.E.l[i]; v1[15 + i] = t1.F.l[i];
         }
+        tree.template feed<P>(bits, v0, v1, out);
+        __builtin_amdgcn_sched_barrier(0);             // two entries per round: left alone the scheduler hoists all 96 reads ahead of the selects
+        if constexpr (P < 3) scan_pair<P + 1>(bits, tree, out);
+    }
+    FQ_DEV PR2 scan_entry(u32 digit) const {
+        const DigitBits<3> bits(digit);
+        SelectTree<20, 3> tree;
+        u32 out[20];
+        scan_pair<0>(bits, tree, out);
         PR2 r;
 #pragma unroll
-        for (int i = 0; i < 5; i++) { r.N.l[i] = acc[i]; r.D.l[i] = acc[5 + i]; r.E.l[i] = acc[10 + i]; r.F.l[i] = acc[15 + i]; }
+        for (int i = 0; i < 5; i++) { r.N.l[i] = out[i]; r.D.l[i] = out[5 + i]; r.E.l[i] = out[10 + i]; r.F.l[i] = out[15 + i]; }
         return r;
     }
     template <bool CT> FQ_DEV PR2 select_entry(u32 digit) const { if constexpr (CT) return scan_entry(digit); else return get_entry(digit); }
