@@ -462,6 +462,22 @@ template <int ALGO, bool DH, bool FIXED = false> int launch_pair(fourq_ctx* c, L
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
 }
+// A mixed batch of at most half a generation: the same kernels with the table chosen per element (kernels.hip.h, pair_kernel<..., MIXED>)
+int launch_pair_mixed(fourq_ctx* c, LadderArgs a) {
+    const bool quad = a.n <= c->quad_max;
+    const size_t per_block = BLOCK / (quad ? 4 : 2);
+    const size_t blocks = ((size_t)a.n + per_block - 1) / per_block;
+    const unsigned grid = (unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus);
+    a.table = c->table_limbs;
+    if (c->ct) {
+        HIPRC_TRY(c, ct_launch_pair_mixed(quad, grid, c->stream, a));
+        return FOURQ_OK;
+    }
+    if (quad) hipLaunchKernelGGL((pair_kernel<ENDO, false, false, false, 4, true>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
+    else hipLaunchKernelGGL((pair_kernel<ENDO, false, false, false, 2, true>), dim3(grid), dim3(BLOCK), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
 // fixed-base batches of at most half a generation: the same two-lanes-per-element kernels on the caller's table (the LDS ladders
 // of fourq_chain.hip take over above that: one lane per element, up to four waves per SIMD)
 bool fixed_takes_pair(const fourq_ctx* c, size_t n) { return c->pair_max && n <= c->pair_max; }
@@ -1080,6 +1096,13 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
     CtxGuard g(c);
     int rc = stage_table(c, table);
     if (rc) return rc;
+    // At most half a generation (and no route forced): one launch of the two- / four-lane kernels, each element on its own kind of
+    // table -- 0.15-0.23 ms where the work-queue kernel takes a one-lane ladder's 0.35 (profiles/r03_quadlane.txt).
+    if (c->mixed_queue < 0 && c->pair_max && n <= c->pair_max) {
+        LadderArgs a = {};
+        a.scalars = s; a.points = p; a.out = o; a.n = (u32)n; a.flags = flags;
+        return launch_pair_mixed(c, a);
+    }
     // Rounds of up to split_chunk elements.  Per round: compact the variable-base ids (count stays on the device),
     // build their tables into scratch slots (prep_kernel over the compacted list), then ONE ladder launch over all
     // elements of the round in their natural order: each lane reads its table through a pointer -- its own slot or

@@ -33,6 +33,11 @@ template <int LPE> int launch_pair_ct_lpe(int algo, bool dh, bool fixed, unsigne
 int ct_launch_pair(int algo, bool dh, bool fixed, bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a) {
     return quad ? launch_pair_ct_lpe<4>(algo, dh, fixed, grid, stream, a) : launch_pair_ct_lpe<2>(algo, dh, fixed, grid, stream, a);
 }
+int ct_launch_pair_mixed(bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a) {
+    if (quad) hipLaunchKernelGGL((pair_kernel<ENDO, false, true, false, 4, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((pair_kernel<ENDO, false, true, false, 2, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
+    return (int)hipGetLastError();
+}
 int ct_launch_mixed_queue(unsigned grid, hipStream_t stream, const LadderArgs& a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head) {
     hipLaunchKernelGGL(mixed_queue_kernel<true>, dim3(grid), dim3(BLOCK), 0, stream, a, var_list, fix_list, counts, queue_head);
     return (int)hipGetLastError();

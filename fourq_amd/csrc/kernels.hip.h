@@ -105,6 +105,7 @@ struct LadderArgs {
     const u64* points;     // variable base: n x 20 (R1) ; DH: n x 8 (affine) ; else unused
     u64* out;              // n x 20 (R1) or n x 8 (affine, DH)
     uint8_t* status;       // DH only
+    const uint8_t* flags;  // mixed batches on the two- and four-lane kernels: flags[i] != 0 = variable base (points[i]), 0 = the fixed-base table
     const u32* index;      // optional: element ids to process (prep_kernel over the variable-base ids of a mixed batch); NULL = identity
     u32 base;              // first position of this launch (chunked large batches)
     const u32* base_dev;   // optional: added to `base`, read on the device (the overflow part of a list whose split is decided on the device)
@@ -583,9 +584,13 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
 // :426; DH still tests it, curve4q.py:447-448).
 // LPE = 4: four lanes per element (pair.hip.h, "four lanes per element"): 64 elements per block, both pairs of an element keep the
 // whole table and every value; the ladder steps share their products between the pairs; the first pair stores.
-template <int ALGO, bool DH, bool CT = false, bool FIXED = false, int LPE = 2>
+// MIXED (BASELINE config 5's batch shape, small): element i takes its table from its own point (flags[i] != 0) or from the caller's
+// fixed-base table -- every lane builds a table (from zeros where the element is fixed-base: no divergence in the long part), then the
+// fixed-base elements overwrite their LDS rows with the caller's entries.  Which kind an element is, is public.
+template <int ALGO, bool DH, bool CT = false, bool FIXED = false, int LPE = 2, bool MIXED = false>
 __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
     static_assert(LPE == 2 || LPE == 4, "two or four lanes per element");
+    static_assert(!MIXED || (ALGO == ENDO && !DH && !FIXED), "mixed batches are MUL_endo batches");
     constexpr bool QUAD = LPE == 4;
     const QuadLane ql{ QUAD && (threadIdx.x & 2) != 0 };
     const bool writer = !ql.second;
@@ -614,12 +619,14 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
         const u32 id = a.base + (it < n ? it : n - 1);           // idle tail pairs redo the last element, store nothing
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
+        bool variable = true;
+        if constexpr (MIXED) variable = a.flags[id] != 0;
         auto half = [&](int c) {                                  // this lane's half of coordinate c of the input point: words 4c + 2 odd, + 1
             const uint4 w = *reinterpret_cast<const uint4*>(a.points + IN_WORDS * (size_t)id + 4 * c + 2 * odd);
             const Fe<1> f = fe_unpack((u64)w.x | ((u64)w.y << 32), (u64)w.z | ((u64)w.w << 32));
             PF<1> r;
 #pragma unroll
-            for (int i = 0; i < 5; i++) { r.l[i] = f.l[i]; FQ_SIGN_UNKNOWN(r.l[i]); }
+            for (int i = 0; i < 5; i++) { r.l[i] = (!MIXED || variable) ? f.l[i] : 0u; FQ_SIGN_UNKNOWN(r.l[i]); }
             return r;
         };
         auto store_half = [&](int c, u64 lo, u64 hi) {
@@ -637,6 +644,18 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
         PR1 Q;
         if constexpr (ALGO == ENDO) {
             if constexpr (!FIXED) pair_build_table_endo<QUAD>(P, tbl, pl, ql);
+            if constexpr (MIXED) {
+                if (!variable) {
+#pragma unroll 1
+                    for (int v = 0; v < PAIR_VALUES; v++) {
+                        const u32* src = a.table + (v >> 2) * R2_LIMBS + (v & 3) * COORD_U32 + 5 * odd;
+                        PF<1> h;
+#pragma unroll
+                        for (int i = 0; i < 5; i++) { h.l[i] = src[i]; FQ_SIGN_UNKNOWN(h.l[i]); }
+                        tbl.put(v, h);
+                    }
+                }
+            }
             u64 v[4];
             decompose(m, v);
             Q = pair_ladder_endo<CT, QUAD>(recode(v), tbl, pl, ql);
@@ -937,6 +956,7 @@ int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 pro
 // constant-time selection builds of the same kernels: fourq_ct_fused.hip (FQ_CHAIN=0) and fourq_ct_chain.hip (FQ_CHAIN=1)
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_pair(int algo, bool dh, bool fixed, bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_pair_mixed(bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
                          u32* over_scratch, u32 lanes, u32 limit);     // split_counts_kernel must already have run: see fourq_ct_chain.hip
 int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit);

@@ -270,13 +270,17 @@ def _kat_p392():
         return unhex(json.load(fh)["P392"])
 
 
-@pytest.mark.parametrize("queue", ["0", "1"])
+@pytest.mark.parametrize("queue", ["0", "1", None])
 def test_mixed_batch_on_both_routes(queue, monkeypatch):
-    """A mixed batch through round 2's three launches (FOURQ_MIXED_QUEUE=0) and through the persistent work-queue kernel
-    (FOURQ_MIXED_QUEUE=1: BASELINE config 5's mechanism), both selection modes, ragged item counts of both kinds."""
+    """A mixed batch through round 2's three launches (FOURQ_MIXED_QUEUE=0), through the persistent work-queue kernel
+    (FOURQ_MIXED_QUEUE=1: BASELINE config 5's mechanism) and by default routing -- at most half a generation: the two- / four-lane
+    kernels with the table chosen per element (pair_kernel<..., MIXED>) -- both selection modes, ragged item counts of both kinds."""
     from fourq_amd import Engine
-    monkeypatch.setenv("FOURQ_MIXED_QUEUE", queue)
-    n = 9001
+    if queue is None:
+        monkeypatch.delenv("FOURQ_MIXED_QUEUE", raising=False)
+    else:
+        monkeypatch.setenv("FOURQ_MIXED_QUEUE", queue)
+    n = 9001 if queue is not None else 40000                                       # default routing: four lanes, two lanes, the queue kernel
     s = seeded_scalars(50011, n)
     flags = (seeded_scalars(50012, n)[:, 0] % 3 == 0).astype(np.uint8)              # a third variable-base
     with Engine(0) as e:
@@ -286,8 +290,12 @@ def test_mixed_batch_on_both_routes(queue, monkeypatch):
         for ct in (False, True):
             e.ct_select = ct
             assert np.array_equal(e.mul_endo_mixed(s, pts, flags, tbl), want), (queue, ct)
-            for m in (1, 63, 64, 65):                                              # fewer elements than one work item / exactly one / one more
+            for m in (1, 63, 64, 65) + ((127, 129, 9001, e.lanes // 4, e.lanes // 4 + 1, e.lanes // 2) if queue is None else ()):   # around the work item / the blocks / the route switches
                 assert np.array_equal(e.mul_endo_mixed(s[:m], pts[:m], flags[:m], tbl), want[:m]), (queue, ct, m)
+            if queue is None:                                                      # all of one kind, on the small-batch kernels
+                m = 3000
+                assert np.array_equal(e.mul_endo_mixed(s[:m], pts[:m], np.zeros(m, np.uint8), tbl), oc.mul(oc.ENDO, s[:m], None, tbl)), ct
+                assert np.array_equal(e.mul_endo_mixed(s[:m], pts[:m], np.ones(m, np.uint8), tbl), oc.mul(oc.ENDO, s[:m], pts[:m])), ct
 
 
 @pytest.mark.parametrize("extra", [0, 300, 9000])
