@@ -18,11 +18,11 @@ def test_constant_time_kernels_have_no_digit_dependent_address_or_branch(tmp_pat
     rows, problems = ct_isa_audit.audit_units(ct_isa_audit.UNITS, str(tmp_path))
     assert not problems, problems[:5]
     kinds = {name for _, name, loops, _ in rows if loops}
-    assert len(kinds) >= 30                                     # 4 fused + 16 pair- and quad-lane + 6 LDS ladders + 2 combs + the mixed-batch queue and tail kernels
-    assert sum(loops for _, _, loops, _ in rows) >= 32
-    # two and four lanes per element x variable and fixed base x MUL / DH x endo / windowed: one ladder loop each
-    assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and "ELi2EEE" in name and loops == 1) == 8
-    assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and "ELi4EEE" in name and loops == 1) == 8
+    assert len(kinds) >= 32                                     # 4 fused + 18 pair- and quad-lane + 6 LDS ladders + 2 combs + the mixed-batch queue and tail kernels
+    assert sum(loops for _, _, loops, _ in rows) >= 34
+    # two and four lanes per element x (variable and fixed base x MUL / DH x endo / windowed + the mixed MUL_endo kernel): one ladder loop each
+    assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and "ELi2ELb" in name and loops == 1) == 9
+    assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and "ELi4ELb" in name and loops == 1) == 9
     assert any("mixed_ct_tail_kernel" in name and loops == 2 for _, name, loops, _ in rows)     # shared table in LDS / per-lane table in memory
     assert any("mixed_queue_kernel" in name and loops == 2 for _, name, loops, _ in rows)      # both kinds of work item
 

@@ -193,7 +193,7 @@ def audit_kernel(name, body):
 
     def mads_of(lo, hi):
         return sum(1 for x in instrs[lo:hi + 1] if x.startswith(("v_mad_u64_u32", "v_mad_i64_i32")))
-    if "pair_kernel" in name and "ELi4EEE" in name:
+    if "pair_kernel" in name and "ELi4ELb" in name:         # pair_kernel<ALGO, DH, CT, FIXED, 4, MIXED>
         def shares(lo, hi):
             return sum(1 for x in instrs[lo:hi + 1] if "quad_perm:[2,3,0,1]" in x)
         ladder = [(lo, hi) for lo, hi in loops if (mads_of(lo, hi), shares(lo, hi)) in QUAD_STEP]
