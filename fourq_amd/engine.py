@@ -7,6 +7,7 @@ return numpy arrays; the `*_dev` entry points take device pointers (ints, or any
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -382,13 +383,16 @@ class Engine:
 
 
 _default = None
+_default_lock = threading.Lock()
 
 
 def default_engine():
     """Process-wide engine on device LOCAL_RANK (or 0).  Raises FourQError when no MI355X is usable."""
     global _default
     if _default is None:
-        _default = Engine()
+        with _default_lock:                    # first calls from several threads at once: one context, not one each
+            if _default is None:
+                _default = Engine()
     return _default
 
 
