@@ -364,8 +364,10 @@ struct fourq_ctx {
     std::vector<hipEvent_t> ticks;     // timing events around the copies of the chunks in flight: four per pipeline slot
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
+    char* zero_copy = nullptr;     // 64 KiB of pinned host memory the kernels of a TINY host call read and write directly (no copy engine)
     fourq_host_stats host_stats = {};
     bool host_bounce = true;       // FOURQ_HOST_BOUNCE=0: hand pageable arrays to hipMemcpyAsync directly (measurement knob)
+    bool host_zero_copy = true;    // FOURQ_HOST_ZERO_COPY=0: tiny host calls through hipMemcpyAsync like the others (measurement knob)
     char err[256] = { 0 };
     mutable std::recursive_mutex mu;   // CtxGuard: calls on one context take turns
 };
@@ -718,6 +720,31 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     // A single chunk (down to the reference-shaped call, a batch of one): copies and kernels in order on the context's own stream.
     // Nothing can overlap, so the three-stream choreography below would only add its cross-stream event hops (50 us) to the call.
     // Calls of at most 1 MiB skip even the four timing events (a few us of a 0.19 ms call): their copy durations read 0.
+    // Tiny calls (the batch of one above all): the arrays fit 64 KiB of pinned host memory that the kernels read and write in
+    // place -- two CPU memcpys of a few hundred bytes instead of three trips through the copy engine (profiles/r03_single_call.txt).
+    constexpr size_t ZERO_COPY_BYTES = 64u << 10;
+    if (chunks == 1 && slot <= ZERO_COPY_BYTES && c->host_zero_copy) {
+        if (!c->zero_copy) {
+            void* zp = nullptr;
+            HIP_TRY(c, hipHostMalloc(&zp, ZERO_COPY_BYTES, hipHostMallocDefault));
+            c->zero_copy = (char*)zp;
+        }
+        char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
+        for (int i = 0; i < n_in; i++) {
+            din[i] = c->zero_copy + off_in[i];
+            memcpy(din[i], in[i].src, n * in[i].stride);
+            st.h2d_bytes += n * in[i].stride;
+        }
+        for (int i = 0; i < n_out; i++) dout[i] = c->zero_copy + off_out[i];
+        if ((rc = launch(din, dout, n))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n_out; i++) {
+            memcpy(out[i].dst, dout[i], n * out[i].stride);
+            st.d2h_bytes += n * out[i].stride;
+        }
+        c->host_stats = st;
+        return FOURQ_OK;
+    }
     if (chunks == 1) {
         const bool timed = slot > (1u << 20);
         char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
@@ -922,6 +949,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         c->split_endo_min = 0;
         if (const char* env = getenv("FOURQ_SPLIT_ENDO_MIN")) { long v = atol(env); if (v >= 0) c->split_endo_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
+        if (const char* env = getenv("FOURQ_HOST_ZERO_COPY")) c->host_zero_copy = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
         c->pair_max = c->lanes / 2;                        // two lanes per element: half a generation fills the chip
@@ -972,6 +1000,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->work) (void)hipFree(c->work);
     if (c->pipe_dev) (void)hipFree(c->pipe_dev);
     if (c->pipe_pin) (void)hipHostFree(c->pipe_pin);
+    if (c->zero_copy) (void)hipHostFree(c->zero_copy);
     if (c->shadow_read) (void)hipEventDestroy(c->shadow_read);
     for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
     for (int i = 0; i < PIPE_SLOTS; i++) {

@@ -116,7 +116,8 @@ int fourq_host_free(fourq_ctx *ctx, void *ptr);
 /* transfer statistics of the context's last host-pointer batch call */
 typedef struct fourq_host_stats {
     double h2d_ms, d2h_ms;          /* summed durations of the chunk copies (HIP events); 0 for a call of at most 1 MiB, which
-                                     * runs in order on the context's stream untimed */
+                                     * runs in order on the context's stream untimed (at most 64 KiB: the kernels read and
+                                     * write a pinned host buffer in place, there are no device copies at all) */
     uint64_t h2d_bytes, d2h_bytes;
     uint32_t chunks;
     int pinned_in, pinned_out;      /* 1: every input / output array was pinned (no bounce copy) */

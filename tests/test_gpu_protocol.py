@@ -187,12 +187,12 @@ def test_host_pipeline_chunks_and_pinned_memory(eng, pinned):
 
 @pytest.mark.parametrize("pinned", [False, True])
 def test_small_host_call_runs_in_order_on_the_context_stream(eng, pinned):
-    """A call of one chunk runs in order on the context's stream instead of the three-stream pipeline; at most 1 MiB (the
-    reference-shaped call is a batch of one) it is not even timed: same results, byte counts reported, copy durations 0; one
-    element more than the limit and the durations are there."""
+    """A call of one chunk runs in order on the context's stream instead of the three-stream pipeline; at most 1 MiB it is not
+    even timed, and at most 64 KiB (the reference-shaped call is a batch of one) the kernels read and write pinned host memory in
+    place: same results, byte counts reported, copy durations 0; one element more than 1 MiB and the durations are there."""
     put = (lambda x: eng.host_array(x)) if pinned else (lambda x: x)
     te = oc.table(oc.ENDO, codec.pack_point(G1))
-    for n in (1, 7, 2977, 2978):                               # 2977 x (32 + 160 + 160) B in 256-byte-aligned arrays: just under 1 MiB; 2978: just over
+    for n in (1, 7, 185, 186, 2977, 2978):                     # 185 x (32 + 160 + 160) B in 256-byte-aligned arrays: the last size the kernels read and write in pinned host memory directly (64 KiB); 2977: just under 1 MiB; 2978: just over
         s = put(seeded_scalars(91, n))
         pts = put(eng.mul_endo_fixed(seeded_scalars(92, n), te))
         got = eng.mul_endo(s, pts)
