@@ -54,8 +54,10 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         knobs["FOURQ_PAIR_MAX"] = rng.choice(["0", "100", "5000"])     # round 3: the two-lanes-per-element kernel off / for tiny tails only
     if rng.random() < 0.3:
+        knobs["FOURQ_HOST_ZERO_COPY"] = "0"                              # tiny host calls through hipMemcpyAsync instead of pinned memory read and written in place
+    if rng.random() < 0.3:
         knobs["FOURQ_QUAD_MAX"] = rng.choice(["0", "64", "1000"])      # the four-lanes-per-element kernels off / for tiny batches and tails only
-    for k in ("FOURQ_PAIR_MAX", "FOURQ_QUAD_MAX", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
+    for k in ("FOURQ_PAIR_MAX", "FOURQ_QUAD_MAX", "FOURQ_HOST_ZERO_COPY", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     with Engine(0) as eng:
