@@ -14,6 +14,7 @@ use `fourq_amd.Engine` (or the `*_batch` helpers below) for throughput.
     phi :318, psi :321, decompose :339, recode :358
 """
 import os
+import threading
 
 import numpy as np
 
@@ -206,9 +207,31 @@ def _combined(kind, *rows):
     return cb(*rows)
 
 
+# DH_*(m, G) on the curve's own generator -- key generation, the commonest DH call -- goes through the fixed-base comb of [392]G
+# (fourq_comb_mul_batch: 6 doublings + 27 mixed additions instead of table construction + 64 steps; the draft allows any method that
+# agrees on all inputs, draft-ladd-cfrg-4q.md:725-729; outputs are affine, hence identical).  FOURQ_COMB_KEYGEN=0 turns it off.
+_COMB_KEYGEN = os.environ.get("FOURQ_COMB_KEYGEN", "1") != "0"
+_g_comb_table = None
+_g_comb_lock = threading.Lock()
+
+
+def _g_comb():
+    global _g_comb_table
+    if _g_comb_table is None:
+        with _g_comb_lock:
+            if _g_comb_table is None:
+                eng = default_engine()
+                g392 = eng.mul_endo(codec.pack_scalars([392]), codec.pack_point((Gx, Gy, (1, 0), Gx, Gy)).reshape(1, 20))[0]
+                _g_comb_table = eng.comb_table(g392)
+    return _g_comb_table
+
+
 def _run_batch(kind, items):
     eng = default_engine()
     cols = [np.concatenate(c) if len(items) > 1 else c[0] for c in zip(*items)]
+    if kind[0] == "keygen":
+        out, status = eng.comb_mul(cols[0], _g_comb())
+        return [(out[i], int(status[i])) for i in range(len(items))]
     if kind[0] == "mul":
         out = (eng.mul_endo if kind[1] == "endo" else eng.mul_windowed)(*cols)
         return [(out[i], None) for i in range(len(items))]
@@ -262,6 +285,15 @@ def _dh(kind, m, P, table):
     (X, Y) = P
     eng = default_engine()
     s = codec.pack_scalars([_reduce_windowed(m) if kind == "windowed" else _check_endo_scalar(m)])
+    if _COMB_KEYGEN and not table and (X, Y) == (Gx, Gy):
+        if _COMBINE:
+            out, status = _combined(("keygen", "comb"), s)
+        else:
+            out, status = eng.comb_mul(s, _g_comb())
+            out, status = out[0], int(status[0])
+        if status:
+            raise Exception(_MSG[status])
+        return codec.unpack_fp2s(out)
     pts = codec.pack_point((X, Y)).reshape(1, 8)
     if table or not _COMBINE:
         out, status = (eng.dh_windowed if kind == "windowed" else eng.dh_endo)(s, pts, codec.pack_table(table) if table else None)

@@ -189,3 +189,30 @@ def test_batched_normalisation_large_batches_pick_a_group(eng):
     for lo in (0, n - 2048):
         want, wst = oc.dh(oc.ENDO, s[lo:lo + 2048], g[:2048])
         assert np.array_equal(fixed[lo:lo + 2048], want)
+
+
+def test_drop_in_key_generation_goes_through_the_comb():
+    """`DH_endo(m, G)` / `DH_windowed(m, G)` on the curve's generator are key generation: the drop-in module computes them with the
+    fixed-base comb of [392]G (draft-ladd-cfrg-4q.md:725-729 allows any method that agrees on all inputs).  Same affine points and
+    the same exception as the reference's algorithm for edge scalars; FOURQ_COMB_KEYGEN=0 gives the general kernels."""
+    from fourq_amd import curve4q as c
+    N = o.N
+    G = (o.Gx, o.Gy)
+    before = c.combine_stats().get("keygen_comb", {"calls": 0})["calls"]
+    ok = [1, 2, 3, N - 1, N + 1, 2 * N + 5, 1 << 255, (1 << 256) - 1, 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef]
+    for m in ok:
+        want = o.DH_endo(m, G)
+        assert c.DH_endo(m, G) == want and c.DH_windowed(m, G) == want, hex(m)
+    for m in (0, N, 2 * N):
+        for dh in (c.DH_endo, c.DH_windowed):
+            with pytest.raises(Exception) as ei:
+                dh(m, G)
+            assert str(ei.value) == "DH computation resulted in neutral point"
+    assert c.DH_windowed(-5, G) == o.DH_windowed(-5, G)                     # any integer: reduced mod N first (curve4q.py:217)
+    assert c.combine_stats()["keygen_comb"]["calls"] - before == 2 * len(ok) + 6 + 1
+    saved = c._COMB_KEYGEN
+    try:
+        c._COMB_KEYGEN = False
+        assert c.DH_endo(ok[-1], G) == o.DH_endo(ok[-1], G)                 # the general kernels agree
+    finally:
+        c._COMB_KEYGEN = saved

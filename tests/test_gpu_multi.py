@@ -185,11 +185,16 @@ def test_concurrent_single_calls_are_combined():
     s, k = seeded_scalars(3001, T * R), seeded_scalars(3002, T * R)
     pts = oc.mul(oc.ENDO, k, None, te)
     want_e, want_w = oc.mul(oc.ENDO, s, pts), oc.mul(oc.WINDOWED, s, pts)
+    from fourq_amd.engine import default_engine
+    aff = default_engine().prim("PT_R1TOAFFINE", pts)             # DH on the points themselves (DH on the generator is key generation: the comb)
+    want_dh, st = oc.dh(oc.ENDO, s, aff)
+    assert not st.any()
     g = np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), T * R, axis=0)
-    want_dh, st = oc.dh(oc.ENDO, s, g)
+    want_kg, st = oc.dh(oc.ENDO, s, g)
     assert not st.any()
     ints = [int.from_bytes(row.tobytes(), "little") for row in s]
     tuples = [codec.unpack_fp2s(row) for row in pts]
+    affs = [codec.unpack_fp2s(row) for row in aff]
     before = {kind: v["calls"] for kind, v in curve4q.combine_stats().items()}
     errors = []
 
@@ -204,7 +209,9 @@ def test_concurrent_single_calls_are_combined():
                     with pytest.raises(Exception, match="Point not on curve"):
                         curve4q.DH_endo(ints[i], ((1, 2), (3, 4)))
                 else:
-                    assert curve4q.DH_endo(ints[i], (constants.Gx, constants.Gy)) == codec.unpack_fp2s(want_dh[i]), "DH_endo"
+                    assert curve4q.DH_endo(ints[i], affs[i]) == codec.unpack_fp2s(want_dh[i]), "DH_endo"
+                    if r % 5 == 1:
+                        assert curve4q.DH_endo(ints[i], (constants.Gx, constants.Gy)) == codec.unpack_fp2s(want_kg[i]), "keygen"
         except BaseException as e:                                     # noqa: BLE001 -- reported by the main thread
             errors.append((t, repr(e)))
 
@@ -217,3 +224,4 @@ def test_concurrent_single_calls_are_combined():
     stats = curve4q.combine_stats()
     assert stats["mul_endo"]["calls"] - before.get("mul_endo", 0) == T * R and stats["dh_endo"]["calls"] - before.get("dh_endo", 0) == T * R
     assert stats["mul_endo"]["batches"] < stats["mul_endo"]["calls"] and stats["mul_endo"]["largest_batch"] > 1
+    assert stats["keygen_comb"]["calls"] - before.get("keygen_comb", 0) == (T - 1) * (R // 5)

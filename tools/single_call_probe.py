@@ -9,8 +9,10 @@ from fourq_amd import curve4q, Engine, codec, default_engine
 G = curve4q.AffineToR1(curve4q.Gx, curve4q.Gy)
 m = 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef
 P = curve4q.MUL_endo(m, G)
+Q = curve4q.R1toAffine(curve4q.MUL_endo(7, G))          # a public key that is not the generator (DH on the generator itself is key generation: the comb)
 for name, fn in (("curve4q.MUL_endo(m, P)", lambda: curve4q.MUL_endo(m, P)), ("curve4q.MUL_windowed(m, P)", lambda: curve4q.MUL_windowed(m, P)),
-                 ("curve4q.DH_endo(m, G)", lambda: curve4q.DH_endo(m, (curve4q.Gx, curve4q.Gy)))):
+                 ("curve4q.DH_endo(m, Q)", lambda: curve4q.DH_endo(m, Q)),
+                 ("curve4q.DH_endo(m, G) [comb]", lambda: curve4q.DH_endo(m, (curve4q.Gx, curve4q.Gy)))):
     for _ in range(20): fn()
     t0 = time.perf_counter()
     for _ in range(300): fn()
