@@ -1259,6 +1259,13 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     CtxGuard g(c);
     if (int rc = stage_comb(c, comb)) return rc;
     const int group = normalize_group(c, n);
+    // At most a quarter generation, selection by address: four lanes per element, entries gathered where the table lies (kernels.hip.h,
+    // comb_quad_kernel): a batch of one 0.107 -> 0.05x ms (profiles/r03_quadlane.txt)
+    if (!c->ct && !group && n <= c->quad_max) {
+        hipLaunchKernelGGL(comb_quad_kernel<0>, dim3((unsigned)((n + BLOCK / 4 - 1) / (BLOCK / 4))), dim3(BLOCK), 0, c->stream, scalars, c->comb_limbs, out, status, (u32)n);
+        HIP_TRY(c, hipGetLastError());
+        return FOURQ_OK;
+    }
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
     if (rc) return rc;
     size_t blocks = (n + BLOCK - 1) / BLOCK, blocks_max = c->lanes_w4 / BLOCK;

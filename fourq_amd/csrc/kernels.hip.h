@@ -812,6 +812,70 @@ constexpr int COMB_BLOCK_MAX = 1024;                          // the fast shape'
 constexpr size_t COMB_FAST_LDS_BYTES = (size_t)CombFast::POINTS * COMB_LDS_U32 * sizeof(u32);
 static_assert(COMB_FAST_LDS_BYTES <= 160 * 1024, "the fast comb table must fit the CU's LDS");
 
+// ---- key generation for small batches: the comb (recode.hip.h, CombFast: 6 doublings + 27 mixed additions) four lanes per element ----
+// comb_kernel stages the 144 KB table into LDS once per block -- nothing when a block works through thousands of elements, a third of
+// the 0.11 ms of a batch of one.  Here every lane gathers ITS HALF of an entry (15 dwords) from the table where it lies (L2), one
+// column ahead of its use, and the element's two pairs share the products of the doubling and of the mixed addition (pair.hip.h):
+// 64 elements per block, no LDS.  Selection by address (the default mode): the constant-time mode keeps comb_kernel<.., true>.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(BLOCK) void comb_quad_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
+    using S = CombFast;
+    const u32 odd = threadIdx.x & 1;
+    const PairLane pl{ odd - 1u, 0u - odd };
+    const QuadLane ql{ (threadIdx.x & 2) != 0 };
+    const u32 it = blockIdx.x * (BLOCK / 4) + threadIdx.x / 4;
+    const bool live = it < n && !ql.second;
+    const u32 id = it < n ? it : n - 1;                       // idle tail quads redo the last element, store nothing
+    u64 m[4];
+    load_scalar(scalars + 4 * (size_t)id, m);
+    const CombDigits<S> c = comb_recode<S>(m);
+    auto column = [&](int t) { return S::E * (t % S::V) + (S::E - 1 - t / S::V); };          // the t-th column in processing order
+    auto entry_half = [&](int t, int coord) {                   // this lane's half of coordinate `coord` of the entry of the t-th column
+        const int col = column(t);
+        const u32* e = comb_limbs + (size_t)((((u32)(t % S::V)) << (S::W - 1)) + comb_index(c, col)) * COMB_ENTRY_U32 + coord * COORD_U32 + 5 * odd;
+        PF<1> h;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { h.l[i] = e[i]; FQ_SIGN_UNKNOWN(h.l[i]); }
+        return h;
+    };
+    PF<1> aN = entry_half(0, 0), aD = entry_half(0, 1), aF = entry_half(0, 2);
+    PR1 Q;
+    PF<1> T;
+    {                                                           // +-A as a point with Z = 2: (N - D, N + D, 2), T = X*Y/Z
+        const u32 neg = comb_neg_mask(c, column(0));
+        PF<1> N, D;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            N.l[k] = __builtin_amdgcn_bitop3_b32(neg, aD.l[k], aN.l[k], 0xCA);
+            D.l[k] = __builtin_amdgcn_bitop3_b32(neg, aN.l[k], aD.l[k], 0xCA);
+        }
+        Q.X = ptighten(psub(N, D)); Q.Y = ptighten(padd(N, D));
+        Q.Z.l[0] = pl.even & 2u; Q.Z.l[1] = Q.Z.l[2] = Q.Z.l[3] = Q.Z.l[4] = 0;
+        Q.Ta = pwiden<3>(Q.X); Q.Tb = pwiden<2>(Q.Y);
+        T = pmul(Q.X, pmul_const(Q.Y, fe2_half_const(), pl), pl);
+    }
+#pragma unroll 1
+    for (int t = 1; t < S::V * S::E; t++) {
+        aN = entry_half(t, 0); aD = entry_half(t, 1); aF = entry_half(t, 2);
+        if (t % S::V == 0) Q = qdbl_point<true>(Q.X, Q.Y, Q.Z, pl, ql, T);
+        Q = qadd_affine_entry(Q, T, aN, aD, aF, comb_neg_mask(c, column(t)), pl, ql);
+    }
+    PF<1> ax, ay;
+    pair_to_affine(Q, pl, ax, ay);
+    ax = pcneg(ax, c.negate);                                   // even scalar: [k]B = -[N - k]B, -(x, y) = (-x, y)
+    u64 x0, x1, y0, y1;
+    pair_canon(ax, x0, x1); pair_canon(ay, y0, y1);
+    const u32 neutral = pair_both(((x0 | x1 | y1) == 0 && y0 == (u64)(pl.even & 1u)) ? 1u : 0u);
+    if (live) {
+        auto store_half = [&](int k, u64 lo, u64 hi) {
+            *reinterpret_cast<uint4*>(out + 8 * (size_t)id + 4 * k + 2 * odd) = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+        };
+        store_half(0, neutral ? 0 : x0, neutral ? 0 : x1);
+        store_half(1, neutral ? 0 : y0, neutral ? 0 : y1);
+        if (!odd) status[id] = neutral ? FOURQ_DH_NEUTRAL : FOURQ_DH_OK;
+    }
+}
+
 #if FQ_CHAIN   // only fourq_chain.hip launches it
 // [m]B, affine, from the comb: 6 doublings + 27 mixed additions per element (constant-time mode: 9 + 49 on the small shape).
 // The block width is the launcher's choice (blockDim.x, a multiple of 64): the table is staged once per block.

@@ -309,6 +309,29 @@ FQ_DEV PR1 qadd_signed_entry(const PR1& Q, const PF<1>& T, const PR2& t, u32 neg
     return r;
 }
 
+// Q + (+-A) for an AFFINE comb entry A = (x+y, y-x, 2dxy) (curve.hip.h, add_affine_table), four lanes per element: the products p.D*a.D, p.N*a.N
+// go one per pair, a.F*T on both, then X = E*F, Y = G*H | Z = F*G, T' = E*H (the next addition's T for nothing).  T in, T' out.
+FQ_DEV PR1 qadd_affine_entry(const PR1& Q, PF<1>& T, const PF<1>& aN, const PF<1>& aD, const PF<1>& aF, u32 neg, const PairLane& pl, const QuadLane& ql) {
+    const u32 pick_n = neg ^ (ql.second ? ~0u : 0u);
+    PF<1> v1;
+#pragma unroll
+    for (int k = 0; k < 5; k++) v1.l[k] = __builtin_amdgcn_bitop3_b32(pick_n, aN.l[k], aD.l[k], 0xCA);
+    const PF<1> r1 = pmul(qsel(ql, psub(Q.Y, Q.X), padd(Q.X, Q.Y)), v1, pl);            // A = p.D*a.D | B = p.N*a.N
+    const PF<1> C = pmul(pcneg(aF, neg), T, pl);
+    PF<1> A, B;
+    qshare(ql, r1, A, B);
+    const PF<2> D = pdbl(Q.Z);
+    const PF<2> E = psub(B, A), H = padd(B, A);
+    const PF<3> F = psub(D, C), G = padd(D, C);
+    PR1 r;
+    const PF<1> r3 = pmul(qsel(ql, E, G), qsel(ql, F, H), pl);                           // X = E*F | Y = G*H
+    const PF<1> r4 = pmul(qsel(ql, F, E), qsel(ql, G, H), pl);                           // Z = F*G | T' = E*H
+    qshare(ql, r3, r.X, r.Y);
+    qshare(ql, r4, r.Z, T);
+    r.Ta = pwiden<3>(E); r.Tb = H;
+    return r;
+}
+
 // ---- the pair's table in LDS -----------------------------------------------------------------------------------------
 // 8 entries x 4 coordinates x 5 limbs per LANE (each lane keeps its half): 640 bytes per lane, 256 lanes = the CU's 160 KiB, so a
 // block is 128 elements and a generation 32 768.  Limb pairs (0,1), (2,3) live in a uint2 region and limb 4 in a u32 region, both

@@ -75,6 +75,37 @@ def test_comb_ragged(eng, n):
     assert not st.any() and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("quad", [True, False])
+def test_small_comb_batches_four_lanes_per_element_and_one(quad, monkeypatch):
+    """Key generation for at most a quarter generation runs four lanes per element with the entries gathered from the table in memory
+    (comb_quad_kernel); FOURQ_QUAD_MAX=0 keeps the one-lane kernel with the table staged in LDS.  Same affine points and verdicts
+    either way: edge scalars (0, N, 2N are the neutral point), ragged sizes around the 64-element block and the route switch, both
+    against the reference-shaped computation."""
+    from fourq_amd import Engine
+    if quad:
+        monkeypatch.delenv("FOURQ_QUAD_MAX", raising=False)
+    else:
+        monkeypatch.setenv("FOURQ_QUAD_MAX", "0")
+    with Engine(0) as e:
+        comb = e.comb_table(codec.pack_point(G1))
+        te = oc.table(oc.ENDO, codec.pack_point(G1))
+        N = o.N
+        edge = [0, 1, 2, 3, N - 1, N, N + 1, 2 * N, 2 * N + 1, 1 << 255, (1 << 256) - 1, 1 << 28, (1 << 28) - 1, (1 << 252) - 1]
+        out, st = e.comb_mul(codec.pack_scalars(edge), comb)
+        for m, got, v in zip(edge, out, st):
+            want = o.R1toAffine(o.MUL_endo(m, G1))
+            if want == (o.Ox, o.Oy):
+                assert v == 2 and not got.any(), hex(m)
+            else:
+                assert v == 0 and codec.unpack_fp2s(got) == want, hex(m)
+        big = e.lanes // 4 + 1
+        s = seeded_scalars(4711, big)
+        want = e.prim("PT_R1TOAFFINE", oc.mul(oc.ENDO, s, None, te))
+        for m in (1, 2, 63, 64, 65, 129, 4097, e.lanes // 4, big):
+            got, v = e.comb_mul(s[:m], comb)
+            assert not v.any() and np.array_equal(got, want[:m]), (quad, m)
+
+
 def test_comb_keygen_then_dh_in_a_hip_graph(eng):
     """Key generation through the comb followed by the peer's variable-base DH on the keys, captured into one HIP graph and
     replayed: the comb's 144 KB of dynamic LDS is granted at context creation, so the launch itself is a pure enqueue."""
