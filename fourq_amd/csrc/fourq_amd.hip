@@ -1261,8 +1261,13 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     const int group = normalize_group(c, n);
     // At most a quarter generation, selection by address: four lanes per element, entries gathered where the table lies (kernels.hip.h,
     // comb_quad_kernel): a batch of one 0.107 -> 0.05x ms (profiles/r03_quadlane.txt)
-    if (!c->ct && !group && n <= c->quad_max) {
-        hipLaunchKernelGGL(comb_quad_kernel<0>, dim3((unsigned)((n + BLOCK / 4 - 1) / (BLOCK / 4))), dim3(BLOCK), 0, c->stream, scalars, c->comb_limbs, out, status, (u32)n);
+    if (!group && n <= c->quad_max) {
+        const unsigned grid = (unsigned)((n + BLOCK / 4 - 1) / (BLOCK / 4));
+        if (c->ct) {
+            HIPRC_TRY(c, ct_launch_comb_quad(grid, c->stream, scalars, c->comb_limbs, out, status, (u32)n));
+            return FOURQ_OK;
+        }
+        hipLaunchKernelGGL(comb_quad_kernel<false>, dim3(grid), dim3(BLOCK), 0, c->stream, scalars, c->comb_limbs, out, status, (u32)n);
         HIP_TRY(c, hipGetLastError());
         return FOURQ_OK;
     }

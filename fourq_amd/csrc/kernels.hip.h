@@ -816,10 +816,33 @@ static_assert(COMB_FAST_LDS_BYTES <= 160 * 1024, "the fast comb table must fit t
 // comb_kernel stages the 144 KB table into LDS once per block -- nothing when a block works through thousands of elements, a third of
 // the 0.11 ms of a batch of one.  Here every lane gathers ITS HALF of an entry (15 dwords) from the table where it lies (L2), one
 // column ahead of its use, and the element's two pairs share the products of the doubling and of the mixed addition (pair.hip.h):
-// 64 elements per block, no LDS.  Selection by address (the default mode): the constant-time mode keeps comb_kernel<.., true>.
-template <int UNUSED = 0>
+// 64 elements per block, no LDS in the default mode.
+// CT: the constant-time shape (80 points, 16-entry blocks; recode.hip.h, CombScan), its 11.5 KB staged into LDS; an addition reads its WHOLE
+// block -- every lane the same addresses but for its half -- and keeps one entry by the select tree (curve.hip.h): no address depends on the scalar.
+template <bool CT, int P, typename TREE, typename BITS> FQ_DEV void comb_scan_pairs(const u32* blk, u32 odd, const BITS& bits, TREE& tree, u32 out[15]) {
+    u32 v0[15], v1[15];
+#pragma unroll
+    for (int cidx = 0; cidx < 3; cidx++) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            v0[5 * cidx + i] = blk[(2 * P) * COMB_ENTRY_U32 + cidx * COORD_U32 + 5 * odd + i];
+            v1[5 * cidx + i] = blk[(2 * P + 1) * COMB_ENTRY_U32 + cidx * COORD_U32 + 5 * odd + i];
+        }
+    }
+    tree.template feed<P>(bits, v0, v1, out);
+    __builtin_amdgcn_sched_barrier(0);                         // two entries per round, as ScanMem
+    if constexpr (2 * P + 2 < CombScan::BLOCK_POINTS) comb_scan_pairs<CT, P + 1>(blk, odd, bits, tree, out);
+}
+template <bool CT = false>
 __global__ __launch_bounds__(BLOCK) void comb_quad_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
-    using S = CombFast;
+    using S = typename std::conditional<CT, CombScan, CombFast>::type;
+    __shared__ __attribute__((aligned(16))) u32 lds_scan[CT ? CombScan::POINTS * COMB_ENTRY_U32 : 4];
+    if constexpr (CT) {
+        const u32* sub = comb_limbs + CombFast::POINTS * COMB_ENTRY_U32;
+        for (u32 i = threadIdx.x; i < (u32)(CombScan::POINTS * COMB_ENTRY_U32 / 4); i += BLOCK)
+            reinterpret_cast<uint4*>(lds_scan)[i] = reinterpret_cast<const uint4*>(sub)[i];
+        __syncthreads();
+    }
     const u32 odd = threadIdx.x & 1;
     const PairLane pl{ odd - 1u, 0u - odd };
     const QuadLane ql{ (threadIdx.x & 2) != 0 };
@@ -830,15 +853,29 @@ __global__ __launch_bounds__(BLOCK) void comb_quad_kernel(const u64* scalars, co
     load_scalar(scalars + 4 * (size_t)id, m);
     const CombDigits<S> c = comb_recode<S>(m);
     auto column = [&](int t) { return S::E * (t % S::V) + (S::E - 1 - t / S::V); };          // the t-th column in processing order
-    auto entry_half = [&](int t, int coord) {                   // this lane's half of coordinate `coord` of the entry of the t-th column
+    auto entry = [&](int t, PF<1>& hN, PF<1>& hD, PF<1>& hF) {  // this lane's halves of the three coordinates of the entry of the t-th column
         const int col = column(t);
-        const u32* e = comb_limbs + (size_t)((((u32)(t % S::V)) << (S::W - 1)) + comb_index(c, col)) * COMB_ENTRY_U32 + coord * COORD_U32 + 5 * odd;
-        PF<1> h;
+        u32 w[15];
+        if constexpr (CT) {
+            const DigitBits<S::W - 1> bits(comb_index(c, col));
+            SelectTree<15, S::W - 1> tree;
+            comb_scan_pairs<CT, 0>(lds_scan + (((u32)(t % S::V)) << (S::W - 1)) * COMB_ENTRY_U32, odd, bits, tree, w);
+        } else {
+            const u32* e = comb_limbs + (size_t)((((u32)(t % S::V)) << (S::W - 1)) + comb_index(c, col)) * COMB_ENTRY_U32 + 5 * odd;
 #pragma unroll
-        for (int i = 0; i < 5; i++) { h.l[i] = e[i]; FQ_SIGN_UNKNOWN(h.l[i]); }
-        return h;
+            for (int cidx = 0; cidx < 3; cidx++) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) w[5 * cidx + i] = e[cidx * COORD_U32 + i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            hN.l[i] = w[i]; hD.l[i] = w[5 + i]; hF.l[i] = w[10 + i];
+            FQ_SIGN_UNKNOWN(hN.l[i]); FQ_SIGN_UNKNOWN(hD.l[i]); FQ_SIGN_UNKNOWN(hF.l[i]);
+        }
     };
-    PF<1> aN = entry_half(0, 0), aD = entry_half(0, 1), aF = entry_half(0, 2);
+    PF<1> aN, aD, aF;
+    entry(0, aN, aD, aF);
     PR1 Q;
     PF<1> T;
     {                                                           // +-A as a point with Z = 2: (N - D, N + D, 2), T = X*Y/Z
@@ -856,7 +893,7 @@ __global__ __launch_bounds__(BLOCK) void comb_quad_kernel(const u64* scalars, co
     }
 #pragma unroll 1
     for (int t = 1; t < S::V * S::E; t++) {
-        aN = entry_half(t, 0); aD = entry_half(t, 1); aF = entry_half(t, 2);
+        entry(t, aN, aD, aF);
         if (t % S::V == 0) Q = qdbl_point<true>(Q.X, Q.Y, Q.Z, pl, ql, T);
         Q = qadd_affine_entry(Q, T, aN, aD, aF, comb_neg_mask(c, column(t)), pl, ql);
     }
@@ -1021,6 +1058,7 @@ int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 pro
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_pair(int algo, bool dh, bool fixed, bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_pair_mixed(bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a);
+int ct_launch_comb_quad(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n);
 int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
                          u32* over_scratch, u32 lanes, u32 limit);     // split_counts_kernel must already have run: see fourq_ct_chain.hip
 int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit);

@@ -90,20 +90,22 @@ def test_small_comb_batches_four_lanes_per_element_and_one(quad, monkeypatch):
         comb = e.comb_table(codec.pack_point(G1))
         te = oc.table(oc.ENDO, codec.pack_point(G1))
         N = o.N
-        edge = [0, 1, 2, 3, N - 1, N, N + 1, 2 * N, 2 * N + 1, 1 << 255, (1 << 256) - 1, 1 << 28, (1 << 28) - 1, (1 << 252) - 1]
-        out, st = e.comb_mul(codec.pack_scalars(edge), comb)
-        for m, got, v in zip(edge, out, st):
-            want = o.R1toAffine(o.MUL_endo(m, G1))
-            if want == (o.Ox, o.Oy):
-                assert v == 2 and not got.any(), hex(m)
-            else:
-                assert v == 0 and codec.unpack_fp2s(got) == want, hex(m)
+        edge = [0, 1, 2, 3, N - 1, N, N + 1, 2 * N, 2 * N + 1, 1 << 255, (1 << 256) - 1, 1 << 28, (1 << 28) - 1, (1 << 50) - 1, 1 << 50, (1 << 252) - 1]
         big = e.lanes // 4 + 1
         s = seeded_scalars(4711, big)
         want = e.prim("PT_R1TOAFFINE", oc.mul(oc.ENDO, s, None, te))
-        for m in (1, 2, 63, 64, 65, 129, 4097, e.lanes // 4, big):
-            got, v = e.comb_mul(s[:m], comb)
-            assert not v.any() and np.array_equal(got, want[:m]), (quad, m)
+        for ct in (False, True):                                  # the constant-time shape (80 points, whole blocks read) has its own quad kernel
+            e.ct_select = ct
+            out, st = e.comb_mul(codec.pack_scalars(edge), comb)
+            for m, got, v in zip(edge, out, st):
+                ref = o.R1toAffine(o.MUL_endo(m, G1))
+                if ref == (o.Ox, o.Oy):
+                    assert v == 2 and not got.any(), (ct, hex(m))
+                else:
+                    assert v == 0 and codec.unpack_fp2s(got) == ref, (ct, hex(m))
+            for m in (1, 2, 63, 64, 65, 129, 4097, e.lanes // 4, big):
+                got, v = e.comb_mul(s[:m], comb)
+                assert not v.any() and np.array_equal(got, want[:m]), (quad, ct, m)
 
 
 def test_comb_keygen_then_dh_in_a_hip_graph(eng):

@@ -10,7 +10,7 @@ import sys
 
 root = sys.argv[1]
 CLASSES = ["random", "zero", "ones", "same"]
-SUBJECT = ("ladder_kernel", "comb_kernel", "normalize_kernel", "prep_kernel", "pair_kernel")
+SUBJECT = ("ladder_kernel", "comb_kernel", "comb_quad_kernel", "normalize_kernel", "prep_kernel", "pair_kernel")
 
 
 def is_ct_kernel(kname):

@@ -193,7 +193,7 @@ def audit_kernel(name, body):
 
     def mads_of(lo, hi):
         return sum(1 for x in instrs[lo:hi + 1] if x.startswith(("v_mad_u64_u32", "v_mad_i64_i32")))
-    if "pair_kernel" in name and "ELi4ELb" in name:         # pair_kernel<ALGO, DH, CT, FIXED, 4, MIXED>
+    if ("pair_kernel" in name and "ELi4ELb" in name) or "comb_quad_kernel" in name:         # pair_kernel<ALGO, DH, CT, FIXED, 4, MIXED>; the comb's quad step = doubling + mixed addition: the same 350 / 35
         def shares(lo, hi):
             return sum(1 for x in instrs[lo:hi + 1] if "quad_perm:[2,3,0,1]" in x)
         ladder = [(lo, hi) for lo, hi in loops if (mads_of(lo, hi), shares(lo, hi)) in QUAD_STEP]
@@ -236,7 +236,7 @@ def audit_units(units, tmp=None):
         if p.wait() != 0:
             raise SystemExit("hipcc failed on %s" % u)
         for name, body in kernels(open(out).read().splitlines()):
-            if not any(k in name for k in ("ladder_kernel", "comb_kernel", "mixed_queue_kernel", "mixed_ct_tail_kernel", "pair_kernel")):
+            if not any(k in name for k in ("ladder_kernel", "comb_kernel", "comb_quad_kernel", "mixed_queue_kernel", "mixed_ct_tail_kernel", "pair_kernel")):
                 continue
             checked, bad = audit_kernel(name, body)
             rows.append((u, name, checked, len(bad)))
