@@ -1261,13 +1261,16 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
     const int group = normalize_group(c, n);
     // At most a quarter generation, selection by address: four lanes per element, entries gathered where the table lies (kernels.hip.h,
     // comb_quad_kernel): a batch of one 0.107 -> 0.05x ms (profiles/r03_quadlane.txt)
-    if (!group && n <= c->quad_max) {
-        const unsigned grid = (unsigned)((n + BLOCK / 4 - 1) / (BLOCK / 4));
+    if (!group && n <= c->pair_max) {         // two lanes per element between a quarter and half a generation: 0.100 -> 0.06x ms
+        const bool quad = n <= c->quad_max;
+        const size_t per_block = BLOCK / (quad ? 4 : 2);
+        const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
         if (c->ct) {
-            HIPRC_TRY(c, ct_launch_comb_quad(grid, c->stream, scalars, c->comb_limbs, out, status, (u32)n));
+            HIPRC_TRY(c, ct_launch_comb_quad(quad, grid, c->stream, scalars, c->comb_limbs, out, status, (u32)n));
             return FOURQ_OK;
         }
-        hipLaunchKernelGGL(comb_quad_kernel<false>, dim3(grid), dim3(BLOCK), 0, c->stream, scalars, c->comb_limbs, out, status, (u32)n);
+        if (quad) hipLaunchKernelGGL((comb_quad_kernel<false, 4>), dim3(grid), dim3(BLOCK), 0, c->stream, scalars, c->comb_limbs, out, status, (u32)n);
+        else hipLaunchKernelGGL((comb_quad_kernel<false, 2>), dim3(grid), dim3(BLOCK), 0, c->stream, scalars, c->comb_limbs, out, status, (u32)n);
         HIP_TRY(c, hipGetLastError());
         return FOURQ_OK;
     }

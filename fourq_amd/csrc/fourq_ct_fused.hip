@@ -38,8 +38,9 @@ int ct_launch_pair_mixed(bool quad, unsigned grid, hipStream_t stream, const Lad
     else hipLaunchKernelGGL((pair_kernel<ENDO, false, true, false, 2, true>), dim3(grid), dim3(BLOCK), 0, stream, a);
     return (int)hipGetLastError();
 }
-int ct_launch_comb_quad(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
-    hipLaunchKernelGGL(comb_quad_kernel<true>, dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, n);
+int ct_launch_comb_quad(bool quad, unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
+    if (quad) hipLaunchKernelGGL((comb_quad_kernel<true, 4>), dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, n);
+    else hipLaunchKernelGGL((comb_quad_kernel<true, 2>), dim3(grid), dim3(BLOCK), 0, stream, scalars, comb_limbs, out, status, n);
     return (int)hipGetLastError();
 }
 int ct_launch_mixed_queue(unsigned grid, hipStream_t stream, const LadderArgs& a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head) {

@@ -833,8 +833,10 @@ template <bool CT, int P, typename TREE, typename BITS> FQ_DEV void comb_scan_pa
     __builtin_amdgcn_sched_barrier(0);                         // two entries per round, as ScanMem
     if constexpr (2 * P + 2 < CombScan::BLOCK_POINTS) comb_scan_pairs<CT, P + 1>(blk, odd, bits, tree, out);
 }
-template <bool CT = false>
+// LPE = 2: two lanes per element (batches between a quarter and half a generation): the same walk on the pair code, T = Ta*Tb inside the addition.
+template <bool CT = false, int LPE = 4>
 __global__ __launch_bounds__(BLOCK) void comb_quad_kernel(const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n) {
+    static_assert(LPE == 2 || LPE == 4, "two or four lanes per element");
     using S = typename std::conditional<CT, CombScan, CombFast>::type;
     __shared__ __attribute__((aligned(16))) u32 lds_scan[CT ? CombScan::POINTS * COMB_ENTRY_U32 : 4];
     if constexpr (CT) {
@@ -845,8 +847,8 @@ __global__ __launch_bounds__(BLOCK) void comb_quad_kernel(const u64* scalars, co
     }
     const u32 odd = threadIdx.x & 1;
     const PairLane pl{ odd - 1u, 0u - odd };
-    const QuadLane ql{ (threadIdx.x & 2) != 0 };
-    const u32 it = blockIdx.x * (BLOCK / 4) + threadIdx.x / 4;
+    const QuadLane ql{ LPE == 4 && (threadIdx.x & 2) != 0 };
+    const u32 it = blockIdx.x * (BLOCK / LPE) + threadIdx.x / LPE;
     const bool live = it < n && !ql.second;
     const u32 id = it < n ? it : n - 1;                       // idle tail quads redo the last element, store nothing
     u64 m[4];
@@ -888,14 +890,20 @@ __global__ __launch_bounds__(BLOCK) void comb_quad_kernel(const u64* scalars, co
         }
         Q.X = ptighten(psub(N, D)); Q.Y = ptighten(padd(N, D));
         Q.Z.l[0] = pl.even & 2u; Q.Z.l[1] = Q.Z.l[2] = Q.Z.l[3] = Q.Z.l[4] = 0;
-        Q.Ta = pwiden<3>(Q.X); Q.Tb = pwiden<2>(Q.Y);
-        T = pmul(Q.X, pmul_const(Q.Y, fe2_half_const(), pl), pl);
+        const PF<1> y_half = pmul_const(Q.Y, fe2_half_const(), pl);
+        Q.Ta = pwiden<3>(Q.X); Q.Tb = pwiden<2>(y_half);        // Ta*Tb = X*Y/Z
+        T = pmul(Q.X, y_half, pl);
     }
 #pragma unroll 1
     for (int t = 1; t < S::V * S::E; t++) {
         entry(t, aN, aD, aF);
-        if (t % S::V == 0) Q = qdbl_point<true>(Q.X, Q.Y, Q.Z, pl, ql, T);
-        Q = qadd_affine_entry(Q, T, aN, aD, aF, comb_neg_mask(c, column(t)), pl, ql);
+        if constexpr (LPE == 4) {
+            if (t % S::V == 0) Q = qdbl_point<true>(Q.X, Q.Y, Q.Z, pl, ql, T);
+            Q = qadd_affine_entry(Q, T, aN, aD, aF, comb_neg_mask(c, column(t)), pl, ql);
+        } else {
+            if (t % S::V == 0) Q = pdbl_point(Q.X, Q.Y, Q.Z, pl);
+            Q = padd_affine_entry(Q, aN, aD, aF, comb_neg_mask(c, column(t)), pl);
+        }
     }
     PF<1> ax, ay;
     pair_to_affine(Q, pl, ax, ay);
@@ -1058,7 +1066,7 @@ int chain_launch_normalize(int k, hipStream_t stream, const uint4* proj, u32 pro
 int ct_launch_fused(int algo, bool dh, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_pair(int algo, bool dh, bool fixed, bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a);
 int ct_launch_pair_mixed(bool quad, unsigned grid, hipStream_t stream, const LadderArgs& a);
-int ct_launch_comb_quad(unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n);
+int ct_launch_comb_quad(bool quad, unsigned grid, hipStream_t stream, const u64* scalars, const u32* comb_limbs, u64* out, uint8_t* status, u32 n);
 int ct_launch_mixed_tail(unsigned prep_grid, unsigned tail_grid, hipStream_t stream, const LadderArgs& a, const u32* fix_list, const u32* var_list, u32* counts,
                          u32* over_scratch, u32 lanes, u32 limit);     // split_counts_kernel must already have run: see fourq_ct_chain.hip
 int ct_launch_split_counts(hipStream_t stream, u32* counts, u32 lanes, u32 limit);

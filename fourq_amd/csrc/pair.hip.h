@@ -332,6 +332,25 @@ FQ_DEV PR1 qadd_affine_entry(const PR1& Q, PF<1>& T, const PF<1>& aN, const PF<1
     return r;
 }
 
+// the same addition two lanes per element (batches between a quarter and half a generation): T = Ta*Tb first, then the seven products in turn
+FQ_DEV PR1 padd_affine_entry(const PR1& Q, const PF<1>& aN, const PF<1>& aD, const PF<1>& aF, u32 neg, const PairLane& pl) {
+    const PF<1> T = pmul(Q.Ta, Q.Tb, pl);
+    PF<1> sN, sD;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        sN.l[k] = __builtin_amdgcn_bitop3_b32(neg, aD.l[k], aN.l[k], 0xCA);
+        sD.l[k] = __builtin_amdgcn_bitop3_b32(neg, aN.l[k], aD.l[k], 0xCA);
+    }
+    const PF<1> A = pmul(psub(Q.Y, Q.X), sD, pl), B = pmul(padd(Q.X, Q.Y), sN, pl), C = pmul(pcneg(aF, neg), T, pl);
+    const PF<2> D = pdbl(Q.Z);
+    const PF<2> E = psub(B, A), H = padd(B, A);
+    const PF<3> F = psub(D, C), G = padd(D, C);
+    PR1 r;
+    r.X = pmul(E, F, pl); r.Y = pmul(G, H, pl); r.Z = pmul(F, G, pl);
+    r.Ta = pwiden<3>(E); r.Tb = H;
+    return r;
+}
+
 // ---- the pair's table in LDS -----------------------------------------------------------------------------------------
 // 8 entries x 4 coordinates x 5 limbs per LANE (each lane keeps its half): 640 bytes per lane, 256 lanes = the CU's 160 KiB, so a
 // block is 128 elements and a generation 32 768.  Limb pairs (0,1), (2,3) live in a uint2 region and limb 4 in a u32 region, both

@@ -18,9 +18,9 @@ def test_constant_time_kernels_have_no_digit_dependent_address_or_branch(tmp_pat
     rows, problems = ct_isa_audit.audit_units(ct_isa_audit.UNITS, str(tmp_path))
     assert not problems, problems[:5]
     kinds = {name for _, name, loops, _ in rows if loops}
-    assert len(kinds) >= 33                                     # 4 fused + 18 pair- and quad-lane + 6 LDS ladders + 2 combs + the quad comb + the mixed-batch queue and tail kernels
-    assert sum(loops for _, _, loops, _ in rows) >= 35
-    assert any("comb_quad_kernel" in name and loops == 1 for _, name, loops, _ in rows)
+    assert len(kinds) >= 34                                     # 4 fused + 18 pair- and quad-lane + 6 LDS ladders + 2 combs + the small-batch comb (two / four lanes) + the mixed-batch queue and tail kernels
+    assert sum(loops for _, _, loops, _ in rows) >= 36
+    assert sum(1 for _, name, loops, _ in rows if "comb_quad_kernel" in name and loops == 1) == 2
     # two and four lanes per element x (variable and fixed base x MUL / DH x endo / windowed + the mixed MUL_endo kernel): one ladder loop each
     assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and "ELi2ELb" in name and loops == 1) == 9
     assert sum(1 for _, name, loops, _ in rows if "pair_kernel" in name and "ELi4ELb" in name and loops == 1) == 9

@@ -75,23 +75,25 @@ def test_comb_ragged(eng, n):
     assert not st.any() and np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("quad", [True, False])
+@pytest.mark.parametrize("quad", ["four, two, one", "two, one", "one lane per element"])
 def test_small_comb_batches_four_lanes_per_element_and_one(quad, monkeypatch):
-    """Key generation for at most a quarter generation runs four lanes per element with the entries gathered from the table in memory
-    (comb_quad_kernel); FOURQ_QUAD_MAX=0 keeps the one-lane kernel with the table staged in LDS.  Same affine points and verdicts
-    either way: edge scalars (0, N, 2N are the neutral point), ragged sizes around the 64-element block and the route switch, both
-    against the reference-shaped computation."""
+    """Key generation for at most a quarter generation runs four lanes per element, up to half a generation two, with the entries
+    gathered from the table in memory (comb_quad_kernel<CT, 4 | 2>); FOURQ_QUAD_MAX=0 keeps the four-lane form out, FOURQ_PAIR_MAX=0
+    leaves the one-lane kernel with the table staged in LDS.  Same affine points and verdicts every way: edge scalars (0, N, 2N are the
+    neutral point), ragged sizes around the blocks and the route switches, both selection modes, against the reference-shaped computation."""
     from fourq_amd import Engine
-    if quad:
-        monkeypatch.delenv("FOURQ_QUAD_MAX", raising=False)
-    else:
+    monkeypatch.delenv("FOURQ_QUAD_MAX", raising=False)
+    monkeypatch.delenv("FOURQ_PAIR_MAX", raising=False)
+    if quad == "two, one":
         monkeypatch.setenv("FOURQ_QUAD_MAX", "0")
+    elif quad == "one lane per element":
+        monkeypatch.setenv("FOURQ_PAIR_MAX", "0")
     with Engine(0) as e:
         comb = e.comb_table(codec.pack_point(G1))
         te = oc.table(oc.ENDO, codec.pack_point(G1))
         N = o.N
         edge = [0, 1, 2, 3, N - 1, N, N + 1, 2 * N, 2 * N + 1, 1 << 255, (1 << 256) - 1, 1 << 28, (1 << 28) - 1, (1 << 50) - 1, 1 << 50, (1 << 252) - 1]
-        big = e.lanes // 4 + 1
+        big = e.lanes // 2 + 1
         s = seeded_scalars(4711, big)
         want = e.prim("PT_R1TOAFFINE", oc.mul(oc.ENDO, s, None, te))
         for ct in (False, True):                                  # the constant-time shape (80 points, whole blocks read) has its own quad kernel
@@ -103,7 +105,7 @@ def test_small_comb_batches_four_lanes_per_element_and_one(quad, monkeypatch):
                     assert v == 2 and not got.any(), (ct, hex(m))
                 else:
                     assert v == 0 and codec.unpack_fp2s(got) == ref, (ct, hex(m))
-            for m in (1, 2, 63, 64, 65, 129, 4097, e.lanes // 4, big):
+            for m in (1, 2, 63, 64, 65, 127, 128, 129, 4097, e.lanes // 4, e.lanes // 4 + 1, e.lanes // 2, big):
                 got, v = e.comb_mul(s[:m], comb)
                 assert not v.any() and np.array_equal(got, want[:m]), (quad, ct, m)
 

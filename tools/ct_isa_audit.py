@@ -193,10 +193,14 @@ def audit_kernel(name, body):
 
     def mads_of(lo, hi):
         return sum(1 for x in instrs[lo:hi + 1] if x.startswith(("v_mad_u64_u32", "v_mad_i64_i32")))
-    if ("pair_kernel" in name and "ELi4ELb" in name) or "comb_quad_kernel" in name:         # pair_kernel<ALGO, DH, CT, FIXED, 4, MIXED>; the comb's quad step = doubling + mixed addition: the same 350 / 35
+    # pair_kernel<ALGO, DH, CT, FIXED, 4, MIXED>; comb_quad_kernel<CT, 4>: the comb's quad step = doubling + mixed addition, the same 350 / 35
+    # (comb_quad_kernel<CT, 2> is the two-lane code: 650 multiply-adds, as a pair-lane ladder step)
+    if ("pair_kernel" in name and "ELi4ELb" in name) or ("comb_quad_kernel" in name and "ELi4EEE" in name):
         def shares(lo, hi):
             return sum(1 for x in instrs[lo:hi + 1] if "quad_perm:[2,3,0,1]" in x)
         ladder = [(lo, hi) for lo, hi in loops if (mads_of(lo, hi), shares(lo, hi)) in QUAD_STEP]
+    elif "comb_quad_kernel" in name:        # <CT, 2>: doubling (250) + T and the addition's seven products (350); hipcc also latches the addition alone (350): the whole column is the subject
+        ladder = [(lo, hi) for lo, hi in loops if mads_of(lo, hi) == 600]
     else:
         ladder = [(lo, hi) for lo, hi in loops if mads_of(lo, hi) in LADDER_MADS]
     # the ladder-step / comb-column loops are the INNERMOST loops with a whole step's multiply-adds (the element loop around
