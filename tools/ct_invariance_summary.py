@@ -15,12 +15,14 @@ SUBJECT = ("ladder_kernel", "comb_kernel", "comb_quad_kernel", "normalize_kernel
 
 def is_ct_kernel(kname):
     """The CT template argument: the last one of ladder_kernel<ALGO, SRC, DH, DEFER, CT> and comb_kernel<.., CT>, the third of
-    pair_kernel<ALGO, DH, CT, FIXED, LPE>; normalize_kernel has no table."""
+    pair_kernel<ALGO, DH, CT, FIXED, LPE, MIXED>, the first of comb_quad_kernel<CT, LPE>; normalize_kernel has no table."""
     if kname.startswith("normalize_kernel"):
         return True
     args = [a.strip() for a in kname[kname.find("<") + 1:kname.rfind(">")].split(",")]
     if kname.startswith("pair_kernel"):
         return len(args) > 2 and args[2] == "true"
+    if kname.startswith("comb_quad_kernel"):          # comb_quad_kernel<CT, lanes per element>
+        return bool(args) and args[0] == "true"
     return bool(args) and args[-1] == "true"
 
 
