@@ -459,6 +459,73 @@ class Bench:
             rec["t(65792)/t(65536)"] = round(rec["65792"] / rec["65536"], 3)
         return rec
 
+    def small_batches(self, d, sizes=(1, 1024), reps=30):
+        """The other operations of the path at small batch sizes (device-resident, HIP events, median of `reps` calls): what a caller
+        pays for ONE reference-shaped call or a small batch -- two / four lanes per element (pair.hip.h), key generation through the comb
+        gathered from memory (comb_quad_kernel), a mixed batch with the table chosen per element.  Outputs of the largest size are
+        compared with the C oracle once."""
+        import numpy as np
+        import torch
+        from fourq_amd import codec
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c as oc
+        eng = self.eng
+        big = max(sizes)
+        scalars, points = d["keep"][0][:big].contiguous(), self.to_dev(d["points_h"][:big])
+        s_h, p_h = d["scalars_h"][:big], d["points_h"][:big]
+        g_h = np.repeat(self.g_aff.reshape(1, 8), big, axis=0)
+        g = self.to_dev(g_h)
+        flags_h = (np.arange(big) & 1).astype(np.uint8)
+        flags = torch.from_numpy(flags_h).to(self.dev)
+        g392 = eng.mul_endo(codec.pack_scalars([392]), self.g1.reshape(1, 20))[0]
+        comb_h = eng.comb_table(g392)
+        eng.comb_stage(comb_h)
+        out = torch.empty((big, 20), dtype=torch.int64, device=self.dev)
+        aff = torch.empty((big, 8), dtype=torch.int64, device=self.dev)
+        st = torch.empty(big, dtype=torch.uint8, device=self.dev)
+        ops = {
+            "MUL_windowed(m, P)": lambda n: eng.mul_windowed_dev(scalars, points, out, n),
+            "DH_endo(m, Q)": lambda n: eng.dh_endo_dev(scalars, g, None, aff, st, n),
+            "keygen: comb of [392]G == DH_endo(m, G)": lambda n: eng.comb_mul_dev(scalars, None, aff, st, n),
+            "MUL_endo(m, G, table) fixed base": lambda n: eng.mul_endo_fixed_dev(scalars, self.table_g, out, n),
+            "MUL_endo mixed 50/50": lambda n: eng.mul_endo_mixed_dev(scalars, points, flags, self.table_g, out, n),
+        }
+        rec = {}
+        for name, fn in ops.items():
+            row = {}
+            for n in sizes:
+                for _ in range(5):
+                    fn(n)
+                times = []
+                for _ in range(reps):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(self.stream)
+                    fn(n)
+                    b.record(self.stream)
+                    torch.cuda.synchronize()
+                    times.append(a.elapsed_time(b))
+                row[str(n)] = round(sorted(times)[len(times) // 2], 4)
+            rec[name] = row
+        # parity of what was just timed, on `big` elements
+        ops["MUL_endo mixed 50/50"](big)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint64)
+        want = np.where(flags_h[:, None] != 0, oc.mul(oc.ENDO, s_h, p_h), oc.mul(oc.ENDO, s_h, None, self.table_g))
+        ok = bool(np.array_equal(got, want))
+        ops["keygen: comb of [392]G == DH_endo(m, G)"](big)
+        torch.cuda.synchronize()
+        kg, kst = aff.cpu().numpy().view(np.uint64), st.cpu().numpy()
+        want_kg, want_st = oc.dh(oc.ENDO, s_h, g_h)
+        ok = ok and bool(np.array_equal(kg, want_kg)) and bool(np.array_equal(kst, want_st))
+        ops["DH_endo(m, Q)"](big)
+        torch.cuda.synchronize()
+        ok = ok and bool(np.array_equal(aff.cpu().numpy().view(np.uint64), want_kg))
+        rec["parity_ok"] = ok
+        rec["unit"] = "ms per call of n elements (device-resident)"
+        if not ok:
+            raise SystemExit("small_batches: outputs differ from the C oracle")
+        return rec
+
     def gather_ms(self, out, n, reps=3):
         """The path's only collective: results gathered to rank 0 (RCCL over xGMI; gloo in rehearsals).  Median of `reps`."""
         import torch
@@ -723,6 +790,8 @@ def main():
             line["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=pcie_reps[args.workload])
         if world == 1 and args.workload == "cfg2" and not args.batch and not args.no_alongside:
             line["size_sweep"] = b.size_sweep(d)
+            if not args.no_parity:
+                line["small_batches"] = b.small_batches(d)
         if ct:
             line["ct_select"] = dict(ct, mode="fourq_ctx_set_ct_select(ctx, 1) on a second context: every ladder step reads the whole table and "
                                               "selects by masks; no address depends on the scalar (DESIGN.md section 10); outputs compared with the "

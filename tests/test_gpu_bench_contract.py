@@ -69,6 +69,10 @@ def test_default_line_has_the_contract_keys():
     assert "masked select" in line["config"]["table_selection"]
     sw = line["size_sweep"]                                        # small batches and remainders run two or four lanes per element: the cliff, driver-visible
     assert sw["1"] < 0.6 * sw["65536"] and sw["1024"] < 0.6 * sw["65536"] and sw["16384"] < sw["32768"] < 0.8 * sw["65536"] and sw["t(65792)/t(65536)"] < 1.75
+    sb = line["small_batches"]                                     # the other operations at 1 and 1 024 elements, checked against the oracle
+    assert sb["parity_ok"] is True
+    assert sb["keygen: comb of [392]G == DH_endo(m, G)"]["1"] < 0.6 * sb["DH_endo(m, Q)"]["1"] < sb["MUL_windowed(m, P)"]["1"]
+    assert sb["MUL_endo mixed 50/50"]["1024"] < 0.8 * sw["65536"] and sb["MUL_endo(m, G, table) fixed base"]["1"] < sw["1"]
     ct = line["ct_select"]                                         # the constant-time mode, driver-visible: same outputs, its price
     assert set(ct) == {"cfg2", "cfg3", "cfg4", "cfg5", "mode"}
     for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
