@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
 RESOURCES_PATH = os.path.join(HERE, "kernel_resources.json")
 # four translation units: FQ_CHAIN=0 / 1 (kernels.hip.h), and the constant-time-selection builds of both flavours
 SOURCES = ["fourq_amd.hip", "fourq_chain.hip", "fourq_ct_fused.hip", "fourq_ct_chain.hip"]
-HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
+HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "pair.hip.h", "ladder_asm.hip.h", "ladder_asm_gfx950.inc", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Rpass-analysis=kernel-resource-usage"]
 
 # (regex on the demangled kernel name, field, predicate, why).  Checked for the product build only (no extra flags).

@@ -16,6 +16,7 @@
 
 #include "../../include/fourq_amd.h"
 #include "curve.hip.h"
+#include "ladder_asm.hip.h"
 #include "recode.hip.h"
 #include "pair.hip.h"
 
@@ -269,6 +270,11 @@ template <typename L = LimbSlots> FQ_DEV void build_table_endo_pipelined(const R
 // (PRELOAD; measured 0.416 ms per 2^16 batch against 0.423 with plain products and 0.463 chained without the preload: hipcc
 // cannot hoist loads across the opaque partial sums).
 constexpr int LADDER_CH = 2;
+// CH = 3: the same signed DAG as hand-scheduled asm bodies (ladder_asm.hip.h, tools/asmgen/gen_ladder_step.py): the fused
+// kernels' ladders, whose lone wave per SIMD pays for every issue slot (profiles/r04_ladder_step.txt).
+#ifndef FQ_LADDER_ASM
+#define FQ_LADDER_ASM 1
+#endif
 // TOUCH: the two-kernel route's ladder reads a lane's table entry (one 128-byte line of its scratch slot) inside the
 // addition, with no registers to spare for issuing the eight loads a doubling ahead (128-VGPR budget).  A one-dword load of the
 // line at the top of the step, result unused, starts the HBM / Infinity-Cache fetch early: the real loads then hit L2.
@@ -286,7 +292,7 @@ template <typename TP> FQ_DEV u32 touch_line(const TP* p) {
 FQ_DEV void touch_done(u32 landing, u32& after) { asm volatile("" : "+v"(after) : "v"(landing)); }
 // a ladder on signed limbs (CH == 2) hands its result back with non-negative limbs
 template <int CH> FQ_DEV R1 ladder_result(const R1& Q) {
-    if constexpr (CH == 2) {
+    if constexpr (CH >= 2) {
         R1 r;
         r.X = fe2_unsign(Q.X); r.Y = fe2_unsign(Q.Y); r.Z = fe2_unsign(Q.Z);
         r.Ta = widen<4>(fe2_unsign(Q.Ta)); r.Tb = widen<2>(fe2_unsign(Q.Tb));
@@ -303,7 +309,14 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
     for (int i = 63; i >= 0; i--) {
         const u32 digit = endo_digit(e, i);
         const TP* entry = tbl + digit * stride;
-        if (PRELOAD) {
+        if constexpr (CH == 3) {                  // the hand-scheduled bodies (ladder_asm.hip.h); the entry is requested ahead of the doubling
+            static_assert(PRELOAD, "the asm bodies take the entry in registers");
+            const u32 neg = endo_neg_mask(e, i);
+            EntryRegs t = load_entry<L>(entry, neg, digit, ef);
+            Fe2<1> T;
+            dblt_asm(Q.X, Q.Y, Q.Z, T);
+            add_asm(Q, T, t, neg);
+        } else if (PRELOAD) {
             const u32 neg = endo_neg_mask(e, i);
             EntryRegs t = load_entry<L>(entry, neg, digit, ef);
             Q = dbl<CH>(Q.X, Q.Y, Q.Z);
@@ -328,7 +341,15 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
         code = win_code_from_window(win_window(w, i));
         const TP* entry = tbl + (code & 7) * stride;
         const u32 neg = (code >> 3) - 1u;
-        if (PRELOAD) {
+        if constexpr (CH == 3) {
+            static_assert(PRELOAD, "the asm bodies take the entry in registers");
+            EntryRegs t = load_entry<L>(entry, neg, code & 7, ef);
+#pragma unroll 1
+            for (int k = 0; k < 3; k++) dbl_asm(Q.X, Q.Y, Q.Z);
+            Fe2<1> T;
+            dblt_asm(Q.X, Q.Y, Q.Z, T);
+            add_asm(Q, T, t, neg);
+        } else if (PRELOAD) {
             EntryRegs t = load_entry<L>(entry, neg, code & 7, ef);
 #pragma unroll 1
             for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
@@ -512,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             }
         }
         R1 Q;
-        constexpr int CH = LADDER_CH;
+        constexpr int CH = (SRC == FUSED && !CT && FQ_LADDER_ASM) ? 3 : LADDER_CH;
         if (ALGO == ENDO) {
             u64 v[4];
             decompose(m, v);
@@ -705,7 +726,7 @@ __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, con
     const u32 var_items = (n_var + 63) / 64, total = var_items + (n_fix + 63) / 64;
     u32* slot = a.scratch + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * NDSlots::SLOT;
     const u32 lane = threadIdx.x & 63;
-    constexpr int CH = LADDER_CH;
+    constexpr int CH = (!CT && FQ_LADDER_ASM) ? 3 : LADDER_CH;
 #pragma unroll 1
     for (;;) {
         u32 item = 0;

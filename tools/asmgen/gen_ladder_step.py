@@ -1,0 +1,540 @@
+#!/usr/bin/env python3
+"""Generator of the HAND-SCHEDULED gfx950 ladder bodies: DBL and ADD of a table entry, the DAG of
+curve4q.py:138-171 on the signed radix-2^26 limbs of fp127.hip.h, each as ONE monolithic inline-asm body.
+
+What the compiler does not get to decide here:
+  * register allocation (temporaries live in a fixed physical range that the asm statement clobbers; a linear scan over the
+    straight-line body assigns them),
+  * the schedule (program order IS issue order: the real and imaginary accumulation chains of a product alternate, the carry
+    of column k is the addend of column k+1's first multiply-add, operand preparation sits right in front of its product),
+  * no opaque fences, hence no hazard s_nop, and no v_accvgpr moves.
+Operand roles are chosen so that every negated imaginary part and every times-8 operand is computed once:
+  DBL level 2 + R1toR3:  X = G*E, Z = G*F, Y = D*F, T = D*E   -> -G.im, -D.im, 8E, 8F           (26 ops for four products)
+  ADD level 2:           X = E*F, Z = G*F, Y = G*H            -> -E.im, -G.im, 8F, 8H           (26 ops for three)
+
+    python tools/asmgen/gen_ladder_step.py > fourq_amd/csrc/ladder_asm_gfx950.inc      (--stats: the instruction census)
+
+Bodies and their operand order (every Fe2 is ten operands: re limbs 0-4, im limbs 0-4):
+  FQ_ASM_DBL    X, Y, Z in/out | limb mask                                  R1/R4 -> (X, Y, Z) of the double
+  FQ_ASM_DBLT   X, Y, Z in/out | T out | limb mask                          the same plus T = Ta*Tb of the double (R1toR3)
+  FQ_ASM_ADD    X, Y, Z in/out | Ta out | Tb out | T in | N, D, E, F in | neg mask | limb mask       ADD_core with +-entry
+  FQ_ASM_STEP   X, Y, Z in/out | Ta out | Tb out | N, D, E, F in | neg mask | limb mask              DBLT + ADD in one body
+"""
+import argparse
+import collections
+import sys
+
+POOL_LO, POOL_HI = 168, 255            # physical VGPRs every body clobbers (peak need: 84); v0-v167 stay the compiler's
+
+
+class V:                                # one 32-bit value
+    __slots__ = ("name", "fixed", "phys", "pair", "half")
+
+    def __init__(self, name, fixed=None):
+        self.name, self.fixed, self.phys, self.pair, self.half = name, fixed, None, None, 0
+
+    def __repr__(self):
+        return self.name
+
+
+class P:                                # an aligned 64-bit pair
+    def __init__(self, name):
+        self.name = name
+        self.lo, self.hi = V(name + ".lo"), V(name + ".hi")
+        self.lo.pair = self.hi.pair = self
+        self.hi.half = 1
+        self.phys = None
+
+
+class Prog:
+    def __init__(self):
+        self.ins = []                   # (mnemonic, template, defs, uses)
+        self.n = 0
+
+    def v(self, name="t"):
+        self.n += 1
+        return V("%s%d" % (name, self.n))
+
+    def p(self, name="p"):
+        self.n += 1
+        return P("%s%d" % (name, self.n))
+
+    def vec(self, name, k=5):
+        return [self.v(name) for _ in range(k)]
+
+    def emit(self, mn, fmt, defs, uses):
+        self.ins.append((mn, fmt, list(defs), list(uses)))
+
+    # ---- instruction helpers (operands: V, P, or int literal) ----
+    def op2(self, mn, d, a, b):         # d = a <op> b   (VOP2, e32 when a is a register/constant and b a VGPR)
+        self.emit(mn, "{mn} {d}, {a}, {b}", [d], [x for x in (a, b) if isinstance(x, V)] + [("fmt", d, a, b)])
+
+    def add(self, d, a, b):
+        self.op2("v_add_u32_e32", d, a, b)
+
+    def sub(self, d, a, b):             # d = a - b
+        self.op2("v_sub_u32_e32", d, a, b)
+
+    def shl(self, d, k, a):
+        self.op2("v_lshlrev_b32_e32", d, k, a)
+
+    def band(self, d, m, a):
+        self.op2("v_and_b32_e32", d, m, a)
+
+    def xor(self, d, a, b):
+        self.op2("v_xor_b32_e32", d, a, b)
+
+    def sel(self, d, m, x, y):          # d = m ? x : y  bitwise
+        self.emit("v_bitop3_b32", "v_bitop3_b32 {0}, {1}, {2}, {3} bitop3:0xca", [d], [m, x, y])
+
+    def mad(self, acc_out, a, b, acc_in):   # 64-bit acc_out = a*b + acc_in (signed); acc_in None -> 0
+        uses = [a, b] + ([acc_in.lo, acc_in.hi] if acc_in is not None else [])
+        self.emit("v_mad_i64_i32", "mad", [acc_out.lo, acc_out.hi], uses + [("mad", acc_out, a, b, acc_in)])
+
+    def ashr64(self, d, k, s):
+        self.emit("v_ashrrev_i64", "ashr", [d.lo, d.hi], [s.lo, s.hi, ("ashr", d, k, s)])
+
+    def lshl_add64(self, d, s, k, c):   # d = (s << k) + c
+        self.emit("v_lshl_add_u64", "lshladd", [d.lo, d.hi], [s.lo, s.hi, c.lo, c.hi, ("lshladd", d, s, k, c)])
+
+    def alignbit(self, d, hi, lo, k):
+        self.emit("v_alignbit_b32", "v_alignbit_b32 {0}, {1}, {2}, %d" % k, [d], [hi, lo])
+
+    def mov0(self, d):
+        self.emit("v_mov_b32_e32", "v_mov_b32_e32 {0}, 0", [d], [])
+
+
+class Fe2:
+    def __init__(self, re, im):
+        self.re, self.im = re, im
+
+
+def fixed_fe2(base):
+    return Fe2([V("op%d" % (base + i), fixed="%%%d" % (base + i)) for i in range(5)],
+               [V("op%d" % (base + 5 + i), fixed="%%%d" % (base + 5 + i)) for i in range(5)])
+
+
+class Body:
+    """One asm body.  `spec` lists the operands in order: (kind, attribute name) with kind 'fe2' (ten operands) or 'u32'."""
+
+    def __init__(self, spec, pairs=False, order="re-im", seq=False, align=1):
+        """pairs: the two products of a formula level run side by side (four accumulation chains instead of two);
+        order: how a column's four multiply-adds per limb are laid out; seq: a column's real chain, then its imaginary chain."""
+        self.g = Prog()
+        self.pairs, self.order, self.seq, self.align = pairs, order, seq, align
+        g = self.g
+        n = 0
+        for kind, name in spec:
+            if kind == "fe2":
+                setattr(self, name, fixed_fe2(n))
+                n += 10
+            else:
+                setattr(self, name, V(name, fixed="%%%d" % n))
+                n += 1
+        self.n_operands = n
+        # two pairs whose high halves stay zero: the zero-extended limb 0 of a product's two components
+        self.zr, self.zi = g.p("zr"), g.p("zi")
+        self.zsets = [(self.zr, self.zi)]
+        if pairs:
+            self.zsets.append((g.p("zr"), g.p("zi")))
+        for zr, zi in self.zsets:
+            zr.permanent = zi.permanent = True
+            g.mov0(zr.hi)
+            g.mov0(zi.hi)
+        self.zsel = 0
+
+    def side_by_side(self, first, second):
+        """Emit two independent products; with `pairs` their instruction streams alternate one for one."""
+        a0 = len(self.g.ins)
+        self.zsel = 0
+        r1 = first()
+        a1 = len(self.g.ins)
+        self.zsel = 1 if self.pairs else 0
+        r2 = second()
+        a2 = len(self.g.ins)
+        self.zsel = 0
+        if self.pairs:
+            A, B = self.g.ins[a0:a1], self.g.ins[a1:a2]
+            merged = []
+            for k in range(max(len(A), len(B))):
+                if k < len(A):
+                    merged.append(A[k])
+                if k < len(B):
+                    merged.append(B[k])
+            self.g.ins[a0:a2] = merged
+        return r1, r2
+
+    # ---- field helpers ----
+    def fe2_new(self, name):
+        return Fe2(self.g.vec(name + "r"), self.g.vec(name + "i"))
+
+    def fe2_add(self, a, b, name="s", out=None):
+        r = out or self.fe2_new(name)
+        for i in range(5):
+            self.g.add(r.re[i], a.re[i], b.re[i])
+        for i in range(5):
+            self.g.add(r.im[i], a.im[i], b.im[i])
+        return r
+
+    def fe2_sub(self, a, b, name="d", out=None):
+        r = out or self.fe2_new(name)
+        for i in range(5):
+            self.g.sub(r.re[i], a.re[i], b.re[i])
+        for i in range(5):
+            self.g.sub(r.im[i], a.im[i], b.im[i])
+        return r
+
+    def neg_im(self, a):                # -a.im  (5 ops)
+        r = self.g.vec("n")
+        for i in range(5):
+            self.g.sub(r[i], 0, a.im[i])
+        return r
+
+    def times8(self, a):                # (8 a.re[1..4], 8 a.im[1..4])   (8 ops); index 0 unused
+        r8, i8 = [None] + self.g.vec("e", 4), [None] + self.g.vec("e", 4)
+        for j in range(1, 5):
+            self.g.shl(r8[j], 3, a.re[j])
+        for j in range(1, 5):
+            self.g.shl(i8[j], 3, a.im[j])
+        return r8, i8
+
+    # ---- the two accumulation chains of one product ----
+    def columns(self, terms_re, terms_im, out):
+        """terms_*[K] = list of (a, b) multiplicand pairs of column K.  Emits the chains with the real and imaginary parts
+        alternating, the carry pass and the fold of the top carry (2^130 == 8).  Writes the ten limbs of `out`."""
+        g = self.g
+        acc_r, acc_i = g.p("ar"), g.p("ai")
+        zr, zi = self.zsets[self.zsel]
+        lr = [zr.lo] + [out.re[k] for k in range(1, 5)]
+        li = [zi.lo] + [out.im[k] for k in range(1, 5)]
+        first = True
+        for K in range(5):
+            tr, ti = terms_re[K], terms_im[K]
+            if self.seq:
+                for n in range(len(tr)):
+                    g.mad(acc_r, tr[n][0], tr[n][1], None if (first and n == 0) else acc_r)
+                for n in range(len(ti)):
+                    g.mad(acc_i, ti[n][0], ti[n][1], None if (first and n == 0) else acc_i)
+            else:
+                for n in range(max(len(tr), len(ti))):
+                    if n < len(tr):
+                        g.mad(acc_r, tr[n][0], tr[n][1], None if (first and n == 0) else acc_r)
+                    if n < len(ti):
+                        g.mad(acc_i, ti[n][0], ti[n][1], None if (first and n == 0) else acc_i)
+            first = False
+            g.band(lr[K], self.mask, acc_r.lo)
+            g.ashr64(acc_r, 26, acc_r)
+            g.band(li[K], self.mask, acc_i.lo)
+            g.ashr64(acc_i, 26, acc_i)
+        # w = 8 * top + limb0 ; limb0' = w & mask ; limb1 += w >> 26
+        for acc, z, o in ((acc_r, zr, out.re), (acc_i, zi, out.im)):
+            g.lshl_add64(acc, acc, 3, z)
+        for acc, z, o in ((acc_r, zr, out.re), (acc_i, zi, out.im)):
+            g.band(o[0], self.mask, acc.lo)
+            t = g.v("c")
+            g.alignbit(t, acc.hi, acc.lo, 26)
+            g.add(o[1], o[1], t)
+
+    def mul(self, a, na_im, b, b8, name="m", out=None):
+        """(a0 + a1 i)(b0 + b1 i): re = a0*b0 + (-a1)*b1, im = a0*b1 + a1*b0; wrap-around terms through 8b."""
+        out = out or self.fe2_new(name)
+        b0x8, b1x8 = b8
+        tr, ti = [], []
+        for K in range(5):
+            r, m = [], []
+            for i in range(5):
+                j = K - i
+                q0 = b.re[j] if j >= 0 else b0x8[j + 5]
+                q1 = b.im[j] if j >= 0 else b1x8[j + 5]
+                if self.order == "share-q":                    # neighbours share the second operand
+                    r += [(a.re[i], q0), (na_im[i], q1)]
+                    m += [(a.im[i], q0), (a.re[i], q1)]
+                else:                                          # neighbours share the first operand
+                    r += [(a.re[i], q0), (na_im[i], q1)]
+                    m += [(a.re[i], q1), (a.im[i], q0)]
+            tr.append(r)
+            ti.append(m)
+        self.columns(tr, ti, out)
+        return out
+
+    def sqr(self, a, wide=False, name="q", out=None):
+        """(a0 + a1 i)^2: re = (a0 - a1)(a0 + a1), im = (2 a0) a1.  wide: 8(a0+a1) would not fit a signed operand, the
+        wrap-around factor is split as (4d)(2s) (wrap_operands_signed of fp127.hip.h)."""
+        g = self.g
+        out = out or self.fe2_new(name)
+        s, d, t = g.vec("s"), g.vec("d"), g.vec("t")
+        for i in range(5):
+            g.add(s[i], a.re[i], a.im[i])
+        for i in range(5):
+            g.sub(d[i], a.re[i], a.im[i])
+        for i in range(5):
+            g.shl(t[i], 1, a.re[i])
+        sw, i8 = [None] + g.vec("e", 4), [None] + g.vec("e", 4)
+        dw = d
+        if wide:
+            dw = [None] + g.vec("w", 4)
+            for i in range(1, 5):
+                g.shl(dw[i], 2, d[i])
+        for j in range(1, 5):
+            g.shl(sw[j], 1 if wide else 3, s[j])
+        for j in range(1, 5):
+            g.shl(i8[j], 3, a.im[j])
+        tr, ti = [], []
+        for K in range(5):
+            r, m = [], []
+            for i in range(5):
+                j = K - i
+                r.append((d[i], s[j]) if j >= 0 else (dw[i], sw[j + 5]))
+                m.append((t[i], a.im[j]) if j >= 0 else (t[i], i8[j + 5]))
+            tr.append(r)
+            ti.append(m)
+        self.columns(tr, ti, out)
+        return out
+
+    # ---- the formulas ----
+    def dbl(self, with_t, out_t=None):
+        """DBL (curve4q.py:138-152) of (X, Y, Z) in place; with_t: also T = E*D = Ta*Tb of the double (R1toR3, :119-126)."""
+        X, Y, Z = self.X, self.Y, self.Z
+        XY = self.fe2_add(X, Y, "xy")
+        A, B = self.side_by_side(lambda: self.sqr(X, name="A"), lambda: self.sqr(Y, name="B"))
+        Zs, W = self.side_by_side(lambda: self.sqr(Z, name="Zs"), lambda: self.sqr(XY, wide=True, name="W"))
+        D = self.fe2_add(A, B, "D")
+        E = self.fe2_sub(W, D, "E")
+        F = self.fe2_sub(B, A, "F")
+        C = self.fe2_add(Zs, Zs, "C")
+        G = self.fe2_sub(C, F, "G")
+        nG, nD = self.neg_im(G), self.neg_im(D)
+        E8, F8 = self.times8(E), self.times8(F)
+        T = None
+        if with_t:
+            T, _ = self.side_by_side(lambda: self.mul(D, nD, E, E8, "T", out=out_t), lambda: self.mul(G, nG, E, E8, out=X))
+        else:
+            self.mul(G, nG, E, E8, out=X)
+        self.side_by_side(lambda: self.mul(D, nD, F, F8, out=Y), lambda: self.mul(G, nG, F, F8, out=Z))
+        return T
+
+    def add(self, T):
+        """ADD_core (curve4q.py:155-175) of (X, Y, Z, T) and +-entry (N, D, E, F): N and D exchanged by masked selects
+        (GFp2.select, fields.py:236-238), -F by a conditional negation; X, Y, Z in place, Ta = E, Tb = H."""
+        g = self.g
+        X2, Y2, Z2 = self.X, self.Y, self.Z
+        N1 = self.fe2_add(X2, Y2, "N1")
+        D1 = self.fe2_sub(Y2, X2, "D1")
+        sN, sD, Fs = self.fe2_new("sN"), self.fe2_new("sD"), self.fe2_new("Fs")
+        for part in ("re", "im"):
+            for i in range(5):
+                g.sel(getattr(sN, part)[i], self.neg, getattr(self.tD, part)[i], getattr(self.tN, part)[i])
+            for i in range(5):
+                g.sel(getattr(sD, part)[i], self.neg, getattr(self.tN, part)[i], getattr(self.tD, part)[i])
+        for part in ("re", "im"):
+            for i in range(5):
+                g.xor(getattr(Fs, part)[i], self.neg, getattr(self.tF, part)[i])
+            for i in range(5):
+                g.sub(getattr(Fs, part)[i], getattr(Fs, part)[i], self.neg)
+        A2, B2 = self.side_by_side(lambda: self.mul(D1, self.neg_im(D1), sD, self.times8(sD), "A2"),
+                                   lambda: self.mul(N1, self.neg_im(N1), sN, self.times8(sN), "B2"))
+        C2, D2 = self.side_by_side(lambda: self.mul(Fs, self.neg_im(Fs), T, self.times8(T), "C2"),
+                                   lambda: self.mul(self.tE, self.neg_im(self.tE), Z2, self.times8(Z2), "D2"))
+        E2 = self.fe2_sub(B2, A2, out=self.Ta)
+        H2 = self.fe2_add(B2, A2, out=self.Tb)
+        F2 = self.fe2_sub(D2, C2, "F2")
+        G2 = self.fe2_add(D2, C2, "G2")
+        nE2, nG2 = self.neg_im(E2), self.neg_im(G2)
+        F28, H28 = self.times8(F2), self.times8(H2)
+        self.side_by_side(lambda: self.mul(E2, nE2, F2, F28, out=self.X), lambda: self.mul(G2, nG2, H2, H28, out=self.Y))
+        self.mul(G2, nG2, F2, F28, out=self.Z)
+
+
+XYZ = [("fe2", "X"), ("fe2", "Y"), ("fe2", "Z")]
+ENTRY = [("fe2", "tN"), ("fe2", "tD"), ("fe2", "tE"), ("fe2", "tF")]
+
+
+def body_dbl():
+    b = Body(XYZ + [("u32", "mask")])
+    b.dbl(False)
+    return b
+
+
+def body_dblt():
+    b = Body(XYZ + [("fe2", "T"), ("u32", "mask")])
+    b.dbl(True, out_t=b.T)
+    return b
+
+
+def body_add():
+    b = Body(XYZ + [("fe2", "Ta"), ("fe2", "Tb"), ("fe2", "T")] + ENTRY + [("u32", "neg"), ("u32", "mask")])
+    b.add(b.T)
+    return b
+
+
+def body_step(**options):
+    b = Body(XYZ + [("fe2", "Ta"), ("fe2", "Tb")] + ENTRY + [("u32", "neg"), ("u32", "mask")], **options)
+    b.add(b.dbl(True))
+    return b
+
+
+# experimental step bodies for tools/microbench/ladder_step.hip (--variants): what the order of the same instructions is worth
+VARIANTS = [("STEP_V3", "H as the assembler lays it out (no placement)", dict(align=0)),
+            ("STEP_V4", "H with every run of multiply-adds at 4 mod 8", dict(align=2)),
+            ("STEP_V5", "two products side by side (four accumulation chains)", dict(pairs=True)),
+            ("STEP_V6", "a column's real chain, then its imaginary chain (dependent neighbours)", dict(seq=True))]
+
+
+BODIES = [("DBL", body_dbl), ("DBLT", body_dblt), ("ADD", body_add), ("STEP", body_step)]
+
+
+def allocate(prog, POOL_LO=POOL_LO):
+    """Linear scan over the straight-line body: temporaries get physical registers POOL_LO..POOL_HI (pairs even-aligned,
+    taken from the top; singles from the bottom).  A register freed by instruction i is reusable from instruction i+1."""
+    def unit(x):                                          # the allocation unit of a value: itself, or its pair
+        return x.pair if x.pair is not None else x
+
+    last = {}
+    for idx, (_, _, defs, uses) in enumerate(prog.ins):
+        for x in list(defs) + [u for u in uses if isinstance(u, V)]:
+            if not x.fixed:
+                last[id(unit(x))] = idx
+    free = set(range(POOL_LO, POOL_HI + 1))
+    peak, pending = 0, []
+
+    def take_single():
+        for r in range(POOL_LO, POOL_HI + 1):
+            if r in free:
+                free.discard(r)
+                return r
+        raise SystemExit("out of temporaries")
+
+    def take_pair():
+        for r in range(POOL_HI - 1, POOL_LO - 1, -2):
+            if r in free and r + 1 in free:
+                free.discard(r)
+                free.discard(r + 1)
+                return r
+        raise SystemExit("out of temporary pairs")
+
+    for idx, (_, _, defs, uses) in enumerate(prog.ins):
+        free.update(pending)
+        pending = []
+        for d in defs:
+            if d.fixed:
+                continue
+            u = unit(d)
+            if u.phys is None:
+                if isinstance(u, P):
+                    u.phys = take_pair()
+                    u.lo.phys, u.hi.phys = u.phys, u.phys + 1
+                else:
+                    u.phys = take_single()
+        peak = max(peak, (POOL_HI - POOL_LO + 1) - len(free))
+        done = set()
+        for x in list(defs) + [u for u in uses if isinstance(u, V)]:
+            if x.fixed:
+                continue
+            u = unit(x)
+            if id(u) in done or getattr(u, "permanent", False):
+                continue
+            done.add(id(u))
+            if u.phys is None:
+                raise SystemExit("use of %s before its definition (instruction %d)" % (x.name, idx))
+            if last[id(u)] == idx:
+                pending += [u.phys, u.phys + 1] if isinstance(u, P) else [u.phys]
+    return peak
+
+
+def reg(x):
+    if isinstance(x, int):
+        return str(x)
+    if x.fixed:
+        return x.fixed
+    return "v%d" % x.phys
+
+
+def preg(p):
+    return "v[%d:%d]" % (p.phys, p.phys + 1)
+
+
+def render(prog):
+    lines = []
+    for mn, fmt, defs, uses in prog.ins:
+        tag = [u for u in uses if isinstance(u, tuple)]
+        if fmt == "mad":
+            _, out, a, b, acc = tag[0]
+            lines.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (preg(out), reg(a), reg(b), preg(acc) if acc is not None else "0"))
+        elif fmt == "ashr":
+            _, d, k, s = tag[0]
+            lines.append("v_ashrrev_i64 %s, %d, %s" % (preg(d), k, preg(s)))
+        elif fmt == "lshladd":
+            _, d, s, k, c = tag[0]
+            lines.append("v_lshl_add_u64 %s, %s, %d, %s" % (preg(d), preg(s), k, preg(c)))
+        elif tag and tag[0][0] == "fmt":
+            _, d, a, b = tag[0]
+            lines.append("%s %s, %s, %s" % (mn, reg(d), reg(a), reg(b)))
+        else:
+            ops = [reg(x) for x in defs] + [reg(u) for u in uses if isinstance(u, V)]
+            lines.append(fmt.format(*ops))
+    return lines
+
+
+def place(lines, mode):
+    """Code placement.  A VOP3 instruction is 8 bytes, an _e32 one 4: after an odd number of 4-byte instructions every following
+    multiply-add straddles an 8-byte fetch boundary.  mode 1: the body starts 8-byte aligned and wherever an 8-byte instruction would
+    start at 4 (mod 8) the nearest 4-byte instruction in front of it is emitted in its 8-byte (_e64) encoding instead -- same
+    instruction count, no padding.  mode 2 (experiment): the opposite, every run of 8-byte instructions starts at 4 (mod 8)."""
+    if not mode:
+        return lines
+    out, off, last32 = [".p2align 3"], 0, None
+    for ln in lines:
+        size = 4 if ln.split()[0].endswith("_e32") else 8
+        if size == 8:
+            want = 0 if mode == 1 else 4
+            if off % 8 != want and last32 is not None:
+                out[last32] = out[last32].replace("_e32", "_e64", 1)
+                off += 4
+            last32 = None
+        else:
+            last32 = len(out)
+        out.append(ln)
+        off += size
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--variants", action="store_true", help="emit the experimental step bodies instead of the product's")
+    args = ap.parse_args()
+    built = []
+    bodies = BODIES if not args.variants else [(n, (lambda o=o: body_step(**o))) for n, _, o in VARIANTS]
+    pool_lo = 128 if args.variants else POOL_LO              # the experiments may use a larger pool
+    for name, make in bodies:
+        b = make()
+        peak = allocate(b.g, pool_lo)
+        lines = place(render(b.g), b.align)
+        built.append((name, b, peak, lines, collections.Counter(ln.split()[0].replace('_e64', '_e32') for ln in lines if not ln.startswith('.'))))
+    if args.stats:
+        for name, b, peak, lines, census in built:
+            lines = [ln for ln in lines if not ln.startswith(".")]
+            print("%-5s %d instructions, %d operands, peak temporaries %d of %d" % (name, len(lines), b.n_operands, peak, POOL_HI - pool_lo + 1))
+            print("      " + "  ".join("%s %d" % kv for kv in census.most_common()))
+        return
+    out = sys.stdout
+    out.write("// GENERATED by tools/asmgen/gen_ladder_step.py -- do not edit (tests/test_host.py checks that it is current).\n")
+    out.write("// Hand-scheduled gfx950 bodies of the ladder's doubling and addition (curve4q.py:138-171); operand order in the generator's docstring.\n")
+    out.write("// Temporaries: v%d-v%d, clobbered by every body.\n" % (pool_lo, POOL_HI))
+    if args.variants:
+        for n, text, _ in VARIANTS:
+            out.write("#define FQ_%s_NAME \"%s\"\n" % (n, text))
+    out.write("#define %s \"vcc\"" % ("FQ_ASM_VARIANT_CLOBBERS" if args.variants else "FQ_ASM_CLOBBERS"))
+    for r in range(pool_lo, POOL_HI + 1):
+        out.write(", \"v%d\"" % r)
+    out.write("\n")
+    for name, b, peak, lines, census in built:
+        out.write("// %s: %d instructions (%s), peak %d temporaries\n" % (name, len(lines), ", ".join("%d %s" % (v, k) for k, v in census.most_common()), peak))
+        out.write("#define FQ_ASM_%s \\\n" % name)
+        for ln in lines:
+            out.write("    \"%s\\n\" \\\n" % ln)
+        out.write("    \"\"\n")
+
+
+if __name__ == "__main__":
+    main()
