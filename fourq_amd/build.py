@@ -25,13 +25,21 @@ RESOURCES_PATH = os.path.join(HERE, "kernel_resources.json")
 SOURCES = ["fourq_amd.hip", "fourq_chain.hip", "fourq_ct_fused.hip", "fourq_ct_chain.hip"]
 HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "pair.hip.h", "ladder_asm.hip.h", "ladder_asm_gfx950.inc", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Rpass-analysis=kernel-resource-usage"]
+# Code placement (tools/asmgen/place_asm.py, profiles/r04_ladder_step.txt): the device code of every translation unit goes through
+# assembly text, where every 8-byte instruction is put on an 8-byte boundary (an _e32 instruction in front of it re-encoded as _e64),
+# and is assembled, linked and bundled by the same tools hipcc drives itself (`hipcc -###` prints the four steps).
+PLACE_TOOL = os.path.normpath(os.path.join(HERE, "..", "tools", "asmgen", "place_asm.py"))
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+BUNDLE_TARGETS = "host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950"
 
 # (regex on the demangled kernel name, field, predicate, why).  Checked for the product build only (no extra flags).
 RESOURCE_POLICY = [
-    (r"ladder_kernel<\d, 2,", "scratch", lambda v: v == 0,
-     "the two-kernel route's ladders must not spill: they run at 4 waves per SIMD on exactly 128 VGPRs"),
-    (r"ladder_kernel<\d, 2,", "occupancy", lambda v: v >= 4, "the two-kernel route's ladders are sized for 4 waves per SIMD"),
-    (r"ladder_kernel<\d, 1, false", "scratch", lambda v: v == 0, "the fixed-base MUL ladders must not spill"),
+    (r"ladder_kernel<\d, 2,", "scratch", lambda v: v == 0, "the two-kernel route's ladders must not spill"),
+    (r"ladder_kernel<\d, 2, true", "occupancy", lambda v: v >= 4, "the two-kernel route's DH ladders are sized for 4 waves per SIMD (128 VGPRs)"),
+    (r"ladder_kernel<\d, 2, false", "occupancy", lambda v: v >= 2, "the two-kernel route's MUL ladders run the asm bodies at 2 waves per SIMD"),
+    (r"ladder_kernel<\d, 1, \w+, \w+, false>", "scratch", lambda v: v == 0, "the fixed-base ladders (MUL and DH) must not spill"),
+    (r"ladder_kernel<\d, 1, \w+, \w+, false>", "occupancy", lambda v: v >= 2, "the fixed-base ladders run the asm bodies at 2 waves per SIMD"),
+    (r"ladder_kernel<\d, 1, \w+, \w+, true>", "scratch", lambda v: v == 0, "the constant-time fixed-base ladders must not spill (their DH flavours are built for 3 waves per SIMD for that)"),
     (r"ladder_kernel<\d, 0,", "scratch", lambda v: v == 0, "the fused variable-base kernels must not spill to memory (AGPR copies are fine)"),
     (r"pair_kernel<", "scratch", lambda v: v == 0, "the two-lanes-per-element kernel must not spill"),
     (r"prep_kernel<0, \w+>\(", "occupancy", lambda v: v >= 2, "prep_kernel<ENDO> hides its read-backs behind a second wave per SIMD"),
@@ -95,8 +103,8 @@ def source_id(extra_flags=()):
     the library (fourq_build_id) so that a profile can say which build it was taken on (bench.py: roofline.traffic_source)."""
     import hashlib
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
-        with open(os.path.normpath(os.path.join(SRC_DIR, f)), "rb") as fh:
+    for f in [os.path.join(SRC_DIR, f) for f in SOURCES + HEADERS] + [PLACE_TOOL]:
+        with open(os.path.normpath(f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
     return h.hexdigest()[:16]
@@ -106,32 +114,64 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(SRC_DIR, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(SRC_DIR, f) for f in SOURCES + HEADERS] + [PLACE_TOOL]
     return any(os.path.getmtime(os.path.normpath(d)) > built for d in deps)
+
+
+def _run(cmd, verbose=False):
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), "\n".join(l for l in proc.stdout.splitlines() if "remark:" not in l)[-6000:]))
+    return proc.stdout
+
+
+def compile_unit(src, obj, flags, verbose=False, place=True):
+    """One translation unit -> object file; returns hipcc's remarks (the kernel resource report).  With `place`, the device code
+    takes the detour through placed assembly text described at PLACE_TOOL."""
+    src_path = os.path.join(SRC_DIR, src)
+    if not place:
+        return _run([_hipcc()] + flags + ["-c", "-o", obj, src_path], verbose)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("place_asm", PLACE_TOOL)
+    place_asm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(place_asm)
+    stem = os.path.splitext(obj)[0]
+    dev_s, placed_s, dev_o, hsaco, fatbin = stem + ".dev.s", stem + ".placed.s", stem + ".dev.o", stem + ".hsaco", stem + ".hipfb"
+    remarks = _run([_hipcc()] + flags + ["--cuda-device-only", "-S", "-o", dev_s, src_path], verbose)
+    stats = place_asm.place_file(dev_s, placed_s)
+    if verbose:
+        print("%s: %d of %d 8-byte instructions at 4 mod 8 before placement, %d after" % (
+            src, stats["misaligned_before"], stats["wide_total"], stats["misaligned_after"]), file=sys.stderr)
+    _run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", placed_s, "-o", dev_o], verbose)
+    _run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", hsaco, dev_o], verbose)
+    _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096", "-targets=" + BUNDLE_TARGETS,
+          "-input=/dev/null", "-input=" + hsaco, "-output=" + fatbin], verbose)
+    host_flags = [f for f in flags if not f.startswith("-Rpass")]
+    _run([_hipcc()] + host_flags + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", "-o", obj, src_path], verbose)
+    for tmp in (dev_s, placed_s, dev_o, hsaco, fatbin):
+        os.remove(tmp)
+    return remarks
 
 
 def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
     """Compile the library if it is missing or older than its sources; returns its path.  `out_path` + `extra_flags`
     build an experiment variant beside the product library (tools/ab_bench.sh compares them on one GPU box); a variant's
-    resource report goes to <out_path>.resources.json and is not policy-checked."""
+    resource report goes to <out_path>.resources.json and is not policy-checked.  The pseudo-flag -DFQ_NO_PLACE=1 builds a
+    variant without the code placement pass."""
     if out_path is None and not force and not is_stale():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     lib_path = out_path or LIB_PATH
     suffix = "" if out_path is None else "." + os.path.splitext(os.path.basename(out_path))[0]
-    objs, procs = [], []
-    build_id = ['-DFQ_BUILD_ID="%s"' % source_id(extra_flags)]
-    for src in SOURCES:                                   # compile the translation units in parallel (~1 min each)
-        obj = os.path.join(SRC_DIR, os.path.splitext(src)[0] + suffix + ".o")
-        cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + build_id + ["-c", "-o", obj, os.path.join(SRC_DIR, src)]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
+    place = "-DFQ_NO_PLACE=1" not in extra_flags
+    flags = HIPCC_FLAGS + list(extra_flags) + ['-DFQ_BUILD_ID="%s"' % source_id(extra_flags)]
+    objs = [os.path.join(SRC_DIR, os.path.splitext(src)[0] + suffix + ".o") for src in SOURCES]
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:      # the translation units in parallel (~1 min each)
+        outs = list(pool.map(lambda so: compile_unit(so[0], so[1], flags, verbose, place), zip(SOURCES, objs)))
     resources = {}
-    for src, cmd, proc in procs:
-        out, _ = proc.communicate()
-        if proc.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), "\n".join(l for l in out.splitlines() if "remark:" not in l)))
+    for src, out in zip(SOURCES, outs):
         raw = parse_resource_remarks(out)
         names = list(raw)
         resources[src] = dict(zip(_demangle(names), (raw[n] for n in names)))

@@ -941,9 +941,11 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = getenv("FOURQ_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) occ = v; }
         c->lanes = (size_t)c->cus * occ * BLOCK;
         c->lanes_w4 = (size_t)c->cus * 4 * BLOCK;
-        // MUL_windowed / DH_* past one fused generation: a second generation of one wave per SIMD costs as much as the first, the
-        // two-kernel route's second wave per SIMD 3-6 % less (profiles/r03_cliff.txt; round 2 switched at two generations)
-        c->split_min = c->lanes + 1;
+        // The two-kernel route (prep_kernel + ladder_kernel<PREBUILT>) for MUL_windowed / DH_* past one fused generation was worth
+        // 3-8 % through round 3; since the fused kernels' ladders run on the hand-scheduled bodies (ladder_asm.hip.h) the fused route is
+        // 3-6 % ahead at every size and config 4's step 4.7 % faster on it (profiles/r04_routes.txt).  The route stays reachable for
+        // experiments (FOURQ_SPLIT_MIN = smallest batch that takes it); mixed batches keep their own use of both kernels.
+        c->split_min = ~(size_t)0;
         if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
         if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
         c->split_endo_min = 0;

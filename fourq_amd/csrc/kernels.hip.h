@@ -275,6 +275,15 @@ constexpr int LADDER_CH = 2;
 #ifndef FQ_LADDER_ASM
 #define FQ_LADDER_ASM 1
 #endif
+// the fixed-base ladders (table in LDS) on the same bodies: 256 VGPRs, two waves per SIMD instead of four
+#ifndef FQ_LDS_ASM
+#define FQ_LDS_ASM 1
+#endif
+// the two-kernel route's MUL ladder likewise (the packed entry requested a doubling ahead, unpacked behind it): mixed batches
+// +3.7 %; its DH flavour, whose gathers run at the memory system's pace, loses 2.5-4 % with two wave slots and keeps four
+#ifndef FQ_PREBUILT_ASM
+#define FQ_PREBUILT_ASM 1
+#endif
 // TOUCH: the two-kernel route's ladder reads a lane's table entry (one 128-byte line of its scratch slot) inside the
 // addition, with no registers to spare for issuing the eight loads a doubling ahead (128-VGPR budget).  A one-dword load of the
 // line at the top of the step, result unused, starts the HBM / Infinity-Cache fetch early: the real loads then hit L2.
@@ -483,8 +492,14 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
 // DEFER (DH only): leave (X, Y, Z) in a.proj for normalize_kernel instead of inverting Z here.
 // CT: constant-time table selection (every entry read at every step); FUSED keeps N, D of the lane's table in registers and
 // scans E, F in the lane's LDS rows, LDS scans the shared table where it lies (PREBUILT is not taken in this mode).
+constexpr int ladder_waves(int src, bool dh, bool ct) {       // wave slots per SIMD a ladder kernel is built for
+    if (src == FUSED) return 1;                                // the endomorphisms' 256 VGPRs and the CU's whole LDS
+    if (!ct && FQ_LADDER_ASM && ((src == LDS && FQ_LDS_ASM) || (src == PREBUILT && FQ_PREBUILT_ASM && !dh))) return 2;   // the asm bodies: 256 VGPRs
+    if (ct && src == LDS && dh) return 3;                      // the scan's select tree + DH's epilogue spill at 128 VGPRs (52-80 bytes per lane)
+    return 4;
+}
 template <int ALGO, int SRC, bool DH, bool DEFER = false, bool CT = false>
-__global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(LadderArgs a) {
+__global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kernel(LadderArgs a) {
     static_assert(!DEFER || DH, "only DH outputs are normalised");
     static_assert(!(CT && SRC == PREBUILT), "the constant-time mode does not take the two-kernel route");
     constexpr bool USE_EF = SRC == FUSED;                      // LdsEF: the CU's whole LDS for one block of a fused kernel
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             }
         }
         R1 Q;
-        constexpr int CH = (SRC == FUSED && !CT && FQ_LADDER_ASM) ? 3 : LADDER_CH;
+        constexpr int CH = ((SRC == FUSED || (SRC == LDS && FQ_LDS_ASM) || (SRC == PREBUILT && FQ_PREBUILT_ASM && !DH)) && !CT && FQ_LADDER_ASM) ? 3 : LADDER_CH;
         if (ALGO == ENDO) {
             u64 v[4];
             decompose(m, v);
@@ -546,9 +561,9 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             } else if constexpr (CT) {
                 Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else if constexpr (SRC == LDS) {
-                Q = ladder_endo<CH>(e, lds_table, LDS_ENTRY_U32);
+                Q = ladder_endo<CH, CH == 3>(e, lds_table, LDS_ENTRY_U32);
             } else {
-                Q = ladder_endo<CH, SRC == FUSED, L, EF, SRC == PREBUILT>(e, tbl, L::ENTRY, ef);
+                Q = ladder_endo<CH, SRC == FUSED || CH == 3, L, EF, SRC == PREBUILT && CH != 3>(e, tbl, L::ENTRY, ef);
             }
         } else {
             const WinScalar w = win_reduce(m);
@@ -560,9 +575,9 @@ __global__ __launch_bounds__(BLOCK, SRC == FUSED ? 1 : 4) void ladder_kernel(Lad
             } else if constexpr (CT) {
                 Q = ladder_windowed_scan<CH>(w, ScanMem<8, u32>{ lds_table, LDS_ENTRY_U32 });
             } else if constexpr (SRC == LDS) {
-                Q = ladder_windowed<CH>(w, lds_table, LDS_ENTRY_U32);
+                Q = ladder_windowed<CH, CH == 3>(w, lds_table, LDS_ENTRY_U32);
             } else {
-                Q = ladder_windowed<CH, SRC == FUSED, L, EF, SRC == PREBUILT>(w, tbl, L::ENTRY, ef);
+                Q = ladder_windowed<CH, SRC == FUSED || CH == 3, L, EF, SRC == PREBUILT && CH != 3>(w, tbl, L::ENTRY, ef);
             }
         }
         if (DH && DEFER) {                                    // one inversion per K elements, later
