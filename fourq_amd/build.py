@@ -118,6 +118,27 @@ def is_stale():
     return any(os.path.getmtime(os.path.normpath(d)) > built for d in deps)
 
 
+FASTCODEC_SRC = os.path.join(SRC_DIR, "fastcodec.c")
+
+
+def fastcodec_path():
+    import sysconfig
+    return os.path.join(HERE, "_fastcodec" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_fastcodec(force=False, verbose=False):
+    """The host-side tuple <-> word packer (csrc/fastcodec.c, a CPython extension; no GPU code) built in-tree with gcc."""
+    import sysconfig
+    out = fastcodec_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(FASTCODEC_SRC):
+        return out
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("no C compiler for fourq_amd/csrc/fastcodec.c")
+    _run([cc, "-O2", "-shared", "-fPIC", "-Wall", "-I" + sysconfig.get_paths()["include"], "-o", out, FASTCODEC_SRC], verbose)
+    return out
+
+
 def _run(cmd, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -160,6 +181,8 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
     build an experiment variant beside the product library (tools/ab_bench.sh compares them on one GPU box); a variant's
     resource report goes to <out_path>.resources.json and is not policy-checked.  The pseudo-flag -DFQ_NO_PLACE=1 builds a
     variant without the code placement pass."""
+    if out_path is None:
+        build_fastcodec(force, verbose)
     if out_path is None and not force and not is_stale():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor

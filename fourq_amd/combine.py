@@ -13,7 +13,7 @@ waiter, which runs the next batch -- so no caller is held back working for other
 Invariants (all under `_lock`): `_busy` is False only while `_queue` is empty; the queue holds exactly the calls no batch has
 taken yet, oldest first; the leader's own call is `_queue[0]` when it takes its batch (it either found the queue empty or
 was promoted as the oldest waiter), so a leader is always served by its own batch; every slot's event is set exactly once,
-either with `done` (served) or without (promoted).
+either with `done` (served) or without (promoted); a waiter that leaves by an exception takes its slot out of the queue (`_abandon`).
 """
 import threading
 
@@ -46,7 +46,11 @@ class Combiner:
             if lead:
                 self._busy = True
         if not lead:
-            slot.event.wait()                                 # woken with its result, or as the next leader
+            try:
+                slot.event.wait()                             # woken with its result, or as the next leader
+            except BaseException:                             # e.g. KeyboardInterrupt in the main thread: leave the queue in order
+                self._abandon(slot)
+                raise
             if slot.done:
                 return self._finish(slot)
         with self._lock:                                      # this thread has the GPU: everything queued up to now is one batch
@@ -80,6 +84,22 @@ class Combiner:
             if heir is not None:
                 heir.event.set()                              # not done: it leads the next batch
         return self._finish(slot)
+
+    def _abandon(self, slot):
+        """A waiter leaves without its result.  Still queued: it is taken out, so that it can never be picked as the next leader (a
+        batch nobody runs would leave `_busy` set and block every later caller).  Already promoted (its event set, not served): the
+        leadership it was handed goes on to the oldest waiter, or is given up.  Already in a running batch: nothing to undo."""
+        heir = None
+        with self._lock:
+            if slot in self._queue:
+                promoted = slot.event.is_set() and not slot.done
+                self._queue.remove(slot)
+                if promoted:
+                    heir = self._queue[0] if self._queue else None
+                    if heir is None:
+                        self._busy = False
+        if heir is not None:
+            heir.event.set()
 
     @staticmethod
     def _finish(slot):

@@ -551,8 +551,21 @@ int shadow_free(fourq_ctx* c) {
     HIP_TRY(c, hipEventSynchronize(c->shadow_read));
     return FOURQ_OK;
 }
+// A table must be staged OUTSIDE a stream capture: the upload would be captured reading the context's mutable shadow at
+// replay time, and shadow_read would become a captured event that no later hipEventSynchronize accepts.  A call that finds
+// its table staged captures fine (it enqueues kernels only); one that would have to stage is refused with a message.
+int staging_allowed(fourq_ctx* c) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (c->stream && hipStreamIsCapturing(c->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+        snprintf(c->err, sizeof c->err, "a table would have to be staged while the stream is being captured: stage it before "
+                 "the capture (one call with the same table, or fourq_comb_stage), then capture");
+        return FOURQ_ERR_HIP;                                 // what the runtime itself would answer (hipErrorStreamCaptureUnsupported), with the reason
+    }
+    return FOURQ_OK;
+}
 int stage_table(fourq_ctx* c, const uint64_t* table_host) {
     if (c->table_staged && memcmp(c->table_shadow, table_host, sizeof c->table_shadow) == 0) return FOURQ_OK;
+    if (int rc = staging_allowed(c)) return rc;
     c->table_staged = false;
     if (int rc = shadow_free(c)) return rc;
     memcpy(c->table_shadow, table_host, sizeof c->table_shadow);
@@ -709,14 +722,6 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
         off_out[i] = slot; slot += align256(chunk * out[i].stride); pin_out[i] = pinned || direct_pageable; bounce |= !pin_out[i];
         st.pinned_out &= pinned ? 1 : 0;
     }
-    const int slots = chunks < (size_t)PIPE_SLOTS ? (int)chunks : PIPE_SLOTS;
-    int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
-    if (rc) return rc;
-    while (c->ticks.size() < 4 * (size_t)PIPE_SLOTS) {
-        hipEvent_t e;
-        HIP_TRY(c, hipEventCreate(&e));
-        c->ticks.push_back(e);
-    }
     // A single chunk (down to the reference-shaped call, a batch of one): copies and kernels in order on the context's own stream.
     // Nothing can overlap, so the three-stream choreography below would only add its cross-stream event hops (50 us) to the call.
     // Calls of at most 1 MiB skip even the four timing events (a few us of a 0.19 ms call): their copy durations read 0.
@@ -732,18 +737,24 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
         char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
         for (int i = 0; i < n_in; i++) {
             din[i] = c->zero_copy + off_in[i];
-            memcpy(din[i], in[i].src, n * in[i].stride);
-            st.h2d_bytes += n * in[i].stride;
+            memcpy(din[i], in[i].src, n * in[i].stride);              // a CPU copy: no h2d / d2h bytes or times are reported for it
         }
         for (int i = 0; i < n_out; i++) dout[i] = c->zero_copy + off_out[i];
-        if ((rc = launch(din, dout, n))) return rc;
+        if (int rc = launch(din, dout, n)) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (int i = 0; i < n_out; i++) {
             memcpy(out[i].dst, dout[i], n * out[i].stride);
-            st.d2h_bytes += n * out[i].stride;
         }
         c->host_stats = st;
         return FOURQ_OK;
+    }
+    const int slots = chunks < (size_t)PIPE_SLOTS ? (int)chunks : PIPE_SLOTS;
+    int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
+    if (rc) return rc;
+    while (c->ticks.size() < 4 * (size_t)PIPE_SLOTS) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreate(&e));
+        c->ticks.push_back(e);
     }
     if (chunks == 1) {
         const bool timed = slot > (1u << 20);
@@ -1232,10 +1243,12 @@ FQ_API int fourq_comb_table(fourq_ctx* c, const uint64_t* p_r1, uint64_t* comb) 
 // comb == NULL: "the table fourq_comb_stage was given" -- staged again from the shadow if the stream has changed since
 static int stage_comb(fourq_ctx* c, const uint64_t* comb) {
     if (!comb) {
-        if (!c->comb_known) return FOURQ_ERR_INVALID;
+        if (!c->comb_known) return FOURQ_ERR_INVALID;          // NULL = "the staged table": there must be one
         if (c->comb_staged) return FOURQ_OK;
+        if (int rc = staging_allowed(c)) return rc;
     } else {
         if (c->comb_staged && memcmp(c->comb_shadow, comb, sizeof c->comb_shadow) == 0) return FOURQ_OK;      // as stage_table
+        if (int rc = staging_allowed(c)) return rc;
         c->comb_staged = false;
         if (int rc = shadow_free(c)) return rc;
         memcpy(c->comb_shadow, comb, sizeof c->comb_shadow);
@@ -1255,7 +1268,6 @@ FQ_API int fourq_comb_stage(fourq_ctx* c, const uint64_t* comb) {
 }
 FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !scalars || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;       // NULL = "the staged table": there must be one
     if (!aligned16(scalars) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     CtxGuard g(c);
@@ -1288,7 +1300,6 @@ FQ_API int fourq_comb_mul_batch_dev(fourq_ctx* c, const uint64_t* scalars, const
 }
 FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !scalars || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     CtxGuard g(c);
     if (int rc = stage_comb(c, comb)) return rc;                                        // compared once, not once per chunk
@@ -1424,7 +1435,6 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
 // dh_exchange with the key-generation half through the comb (bench.py's cfg4 step as one call)
 FQ_API int fourq_dh_exchange_comb_batch_dev(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !a || !b || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (!aligned16(a) || !aligned16(b) || !aligned16(out)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     CtxGuard g(c);
@@ -1440,7 +1450,6 @@ FQ_API int fourq_dh_exchange_comb_batch_dev(fourq_ctx* c, const uint64_t* a, con
 }
 FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const uint64_t* b, const uint64_t* comb, uint64_t* out, uint8_t* status, size_t n) {
     if (!c || !a || !b || !out || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
-    if (!comb && !c->comb_known) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     CtxGuard g(c);
     if (int rc = stage_comb(c, comb)) return rc;                            // compared once, not once per chunk

@@ -104,7 +104,11 @@ int fourq_ctx_lanes(const fourq_ctx *ctx, size_t *lanes);
  * decoded keys, first-half results); they grow on demand, and a _dev call whose batch is larger than any seen before
  * SYNCHRONISES the context's stream and reallocates before it enqueues (such a call cannot be captured into a HIP graph).
  * fourq_ctx_reserve(ctx, n) sizes them once for batches of up to n elements: afterwards _dev calls of at most n elements
- * only enqueue.  (The host-pointer calls size their pipeline slots themselves and are synchronous anyway.) */
+ * only enqueue.  (The host-pointer calls size their pipeline slots themselves and are synchronous anyway.)
+ * Capturing _dev calls into a HIP graph: reserve first, and STAGE the caller's tables first -- a fixed-base table or a comb is
+ * uploaded from a context-owned host copy when it differs from what is staged, and that upload must not be captured (it would
+ * read the mutable copy at replay time).  One un-captured call with the same table (or fourq_comb_stage) stages it; a call that
+ * would have to stage while its stream is being captured returns FOURQ_ERR_HIP with fourq_last_error() saying so. */
 int fourq_ctx_reserve(fourq_ctx *ctx, size_t n);
 
 /* Pinned (page-locked) host memory.  The host-pointer batch calls cut their arrays into chunks and overlap the
@@ -118,7 +122,7 @@ typedef struct fourq_host_stats {
     double h2d_ms, d2h_ms;          /* summed durations of the chunk copies (HIP events); 0 for a call of at most 1 MiB, which
                                      * runs in order on the context's stream untimed (at most 64 KiB: the kernels read and
                                      * write a pinned host buffer in place, there are no device copies at all) */
-    uint64_t h2d_bytes, d2h_bytes;
+    uint64_t h2d_bytes, d2h_bytes;  /* bytes moved by device copies: 0 for such an in-place call */
     uint32_t chunks;
     int pinned_in, pinned_out;      /* 1: every input / output array was pinned (no bounce copy) */
 } fourq_host_stats;

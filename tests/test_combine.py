@@ -129,3 +129,81 @@ def test_many_threads_many_calls():
         t.join(60)
     st = cb.stats()
     assert not bad and st["calls"] == 3200 and st["batches"] < 3200 and 1 < st["largest_batch"] <= 16
+
+
+def test_a_waiter_that_leaves_by_an_exception_does_not_block_later_callers(monkeypatch):
+    """a waiter interrupted inside event.wait() (KeyboardInterrupt in the main thread) used to stay in the queue; picked
+    as the next leader later, nobody ran its batch and every following call blocked.  Both cases: interrupted while still queued
+    behind a running batch, and interrupted after having been promoted to lead the next one."""
+    import fourq_amd.combine as combine
+
+    class Interrupted(BaseException):
+        pass
+
+    for when in ("queued", "promoted"):
+        gate, first_in, waiting = threading.Event(), threading.Event(), threading.Event()
+
+        class Slot(combine._Slot):
+            def __init__(self, args):
+                super().__init__(args)
+                if args == ("victim",):
+                    real_wait = self.event.wait
+
+                    def wait(timeout=None):
+                        waiting.set()
+                        if when == "promoted":
+                            real_wait(30)                 # woken as the next leader ... and interrupted right then
+                        raise Interrupted()
+                    self.event.wait = wait
+
+        monkeypatch.setattr(combine, "_Slot", Slot)
+        sizes = []
+
+        def run(items):
+            sizes.append(len(items))
+            if len(sizes) == 1:
+                first_in.set()
+                assert gate.wait(30)
+            return [x for (x,) in items]
+
+        cb = Combiner(run)
+        out = {}
+        t0 = threading.Thread(target=lambda: out.setdefault("first", cb("first")))
+        t0.start()
+        assert first_in.wait(30)
+
+        def victim():
+            try:
+                cb("victim")
+            except Interrupted:
+                out["victim"] = "interrupted"
+        tv = threading.Thread(target=victim)
+        tv.start()
+        assert waiting.wait(30)
+        if when == "queued":
+            tv.join(30)                                   # it has left the queue before the first batch ends
+        t1 = threading.Thread(target=lambda: out.setdefault("late", cb("late")))
+        t1.start()
+        time.sleep(0.05)
+        gate.set()
+        for t in (t0, tv, t1):
+            t.join(30)
+            assert not t.is_alive(), "a caller is blocked (%s)" % when
+        assert out == {"first": "first", "victim": "interrupted", "late": "late"}
+        assert cb("after") == "after"                     # and the combiner is idle again: a lone call leads at once
+        assert not cb._busy and not cb._queue
+
+
+def test_suite_is_clean_in_python_development_mode():
+    """this file's threads, locks and events under `python -X dev` with faulthandler (unjoined threads, unclosed
+    resources and misuse of the threading primitives become visible there) -- run as a child process, warnings as errors."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("FOURQ_COMBINE_DEV_CHILD"):
+        return
+    env = dict(os.environ, PYTHONDEVMODE="1", PYTHONFAULTHANDLER="1", FOURQ_COMBINE_DEV_CHILD="1")
+    proc = subprocess.run([sys.executable, "-X", "dev", "-X", "faulthandler", "-W", "error::ResourceWarning", "-m", "pytest", "-q", "-x",
+                           "-p", "no:cacheprovider", os.path.abspath(__file__)], capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert "Fatal Python error" not in proc.stderr

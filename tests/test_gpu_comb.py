@@ -193,3 +193,38 @@ def test_reserved_context_is_capturable_without_a_warm_up_call(monkeypatch):
         e.comb_mul_dev(b, None, keys, st1, n)
         e.sync()
         assert np.array_equal(keys.cpu().numpy().view(np.uint64), want_keys)
+
+
+def test_staging_a_table_inside_a_capture_is_refused_with_a_message():
+    """a table that has to be uploaded must be staged outside a stream capture (the upload would be captured reading the
+    context's mutable host copy, and the event that guards that copy would become a captured event).  The call says so and the
+    context stays usable."""
+    import torch
+    from fourq_amd import Engine, FourQError
+    dev = torch.device("cuda", 0)
+    n = 2048
+    s_h = seeded_scalars(91, n)
+    side = torch.cuda.Stream(device=dev)
+    with Engine(0, stream=side.cuda_stream) as e:
+        comb = e.comb_table(codec.pack_point(o.MUL_endo(392, G1)))
+        te = e.table_endo(codec.pack_point(G1))
+        s = torch.from_numpy(s_h.view(np.int64)).to(dev)
+        keys = torch.zeros((n, 8), dtype=torch.int64, device=dev)
+        out = torch.zeros((n, 20), dtype=torch.int64, device=dev)
+        st = torch.empty(n, dtype=torch.uint8, device=dev)
+        e.sync()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            graph.capture_begin()
+            try:
+                with pytest.raises(FourQError, match="staged while the stream is being captured"):
+                    e.comb_mul_dev(s, comb, keys, st, n)                   # nothing staged yet
+                with pytest.raises(FourQError, match="staged while the stream is being captured"):
+                    e.mul_endo_fixed_dev(s, te, out, n)
+            finally:
+                graph.capture_end()
+        e.comb_mul_dev(s, comb, keys, st, n)                               # outside: stages and runs
+        e.sync()
+        gaff = np.repeat(codec.pack_point((o.Gx, o.Gy)).reshape(1, 8), n, axis=0)
+        want, wst = oc.dh(oc.ENDO, s_h, gaff)
+        assert not wst.any() and np.array_equal(keys.cpu().numpy().view(np.uint64), want)

@@ -41,6 +41,49 @@ def test_generated_device_constants_are_current():
     assert open(path).read() == before
 
 
+def test_generated_ladder_bodies_are_current():
+    """fourq_amd/csrc/ladder_asm_gfx950.inc must be what tools/asmgen/gen_ladder_step.py emits (the hand-scheduled ladder bodies)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asmgen", "gen_ladder_step.py")], check=True, capture_output=True, text=True).stdout
+    assert out == open(os.path.join(ROOT, "fourq_amd", "csrc", "ladder_asm_gfx950.inc")).read()
+
+
+def test_every_included_file_is_a_tracked_dependency_of_the_build():
+    """pair.hip.h was included by kernels.hip.h but missing from build.py's HEADERS, so an edit to it neither rebuilt the
+    library nor changed fourq_build_id.  Every #include "..." reachable from the translation units must be in SOURCES + HEADERS."""
+    import re
+    from fourq_amd import build
+    known = {os.path.normpath(os.path.join(build.SRC_DIR, f)) for f in build.SOURCES + build.HEADERS}
+    todo, seen = [os.path.join(build.SRC_DIR, f) for f in build.SOURCES], set()
+    while todo:
+        path = os.path.normpath(todo.pop())
+        if path in seen:
+            continue
+        seen.add(path)
+        assert path in known, "%s is included by the build but not tracked in fourq_amd/build.py" % os.path.relpath(path, ROOT)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M):
+            todo.append(os.path.join(os.path.dirname(path), inc))
+    assert os.path.exists(build.PLACE_TOOL) and build.is_stale() in (True, False)
+
+
+def test_tuple_codec_is_fast_enough_to_be_worth_swapping_in():
+    """the tuple-level API spent 4.5 + 5.6 us per element packing and unpacking in Python loops.  With
+    csrc/fastcodec.c (built in-tree by build()) an R1 point + scalar packs and an R1 point unpacks in well under a microsecond on this
+    container's CPU; the floor here is loose enough for a loaded box (best of 5) and tight enough to catch a fall back to Python."""
+    import random
+    import time
+    assert codec._fc is not None, "fourq_amd/_fastcodec*.so is not built: run __graft_entry__.build()"
+    rnd = random.Random(5)
+    n = 20000
+    pts = [tuple((rnd.randrange(constants.P127), rnd.randrange(constants.P127)) for _ in range(5)) for _ in range(n)]
+    ms = [rnd.getrandbits(256) for _ in range(n)]
+    pack = unpack = 1e9
+    for _ in range(5):
+        t = time.perf_counter(); arr = codec.pack_points(pts, 5); sc = codec.pack_scalars(ms); pack = min(pack, time.perf_counter() - t)
+        t = time.perf_counter(); back = codec.unpack_points(arr); unpack = min(unpack, time.perf_counter() - t)
+    assert back == pts and codec.unpack_scalars(sc) == ms
+    assert pack / n < 1.5e-6 and unpack / n < 1.5e-6, (pack / n, unpack / n)
+
+
 def test_codec_roundtrip(golden):
     rows = golden("mul.json")["var"]
     pts = [r[1] for r in rows]
