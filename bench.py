@@ -250,16 +250,54 @@ def valu_roofline(wl, n, kernel_ms):
 
 
 # ---- one workload on this rank ---------------------------------------------------------------------------------
+class _Cuda:
+    """The few things the rank body needs from torch.cuda and from the engine, behind one object: tests/test_dist.py replaces it
+    with a CPU stand-in to run the N > 1 body (barriers, the MAX over ranks, the gather, the all-ranks parity reduction, the JSON
+    line) over gloo where there is no GPU.  Product runs never see anything but this class."""
+
+    def set_device(self, index):
+        import torch
+        torch.cuda.set_device(index)
+
+    def device(self, index):
+        import torch
+        return torch.device("cuda", index)
+
+    def new_stream(self, device):
+        import torch
+        stream = torch.cuda.Stream(device=device)      # a real (non-null) stream: the engine launches on it, the events time it
+        torch.cuda.set_stream(stream)
+        return stream
+
+    def synchronize(self):
+        import torch
+        GPU.synchronize()
+
+    def event(self):
+        import torch
+        return GPU.event()
+
+    def empty_cache(self):
+        import torch
+        GPU.empty_cache()
+
+    def engine(self, index, stream):
+        from fourq_amd import Engine
+        return Engine(index, stream=stream.cuda_stream)
+
+
+GPU = _Cuda()
+
+
 class Bench:
     def __init__(self, rank, local_rank, world, rehearse):
-        import torch
-        from fourq_amd import Engine, codec, constants
+        from fourq_amd import codec, constants
         self.rank, self.world, self.rehearse = rank, world, rehearse
-        torch.cuda.set_device(local_rank)
-        self.dev = torch.device("cuda", local_rank)
-        self.stream = torch.cuda.Stream(device=self.dev)     # a real (non-null) stream: the engine launches on it, the events time it
-        torch.cuda.set_stream(self.stream)
-        self.eng = Engine(local_rank, stream=self.stream.cuda_stream)
+        GPU.set_device(local_rank)
+        self.local_rank = local_rank
+        self.dev = GPU.device(local_rank)
+        self.stream = GPU.new_stream(self.dev)
+        self.eng = GPU.engine(local_rank, self.stream)
         G_aff = (constants.Gx, constants.Gy)
         self.g1 = codec.pack_point(G_aff + ((1, 0),) + G_aff)
         self.g_aff = codec.pack_point(G_aff)
@@ -291,7 +329,7 @@ class Bench:
         if workload in ("cfg2", "cfg5"):
             points = torch.empty((n, 20), dtype=torch.int64, device=self.dev)
             eng.mul_endo_fixed_dev(second, self.table_g, points, n)          # P_i = [k_i]G, raw R1 (projective, Z != 1)
-            torch.cuda.synchronize()
+            GPU.synchronize()
             d["points_h"] = points.cpu().numpy().view(np.uint64)
         if workload == "cfg2":
             def step():
@@ -332,7 +370,7 @@ class Bench:
         import torch.distributed as dist
         wl = WORKLOADS[workload]
         step, d = self.prepare(workload, n)
-        torch.cuda.synchronize()
+        GPU.synchronize()
         # The clock governor needs ~35 ms of load to reach the sustained clock (tools/clock_ramp.py,
         # profiles/clock_ramp_r01.txt: 0.43 ms per launch cold, 0.364 ms from launch 100 on).  Throughput is a
         # sustained-rate metric, so the device is brought to that state before the W warm-up steps; untimed.
@@ -340,23 +378,23 @@ class Bench:
         while (time.perf_counter() - t_settle) * 1e3 < self.settle_ms:
             for _ in range(8 if n <= 1 << 17 else 1):
                 step()
-            torch.cuda.synchronize()
+            GPU.synchronize()
         for _ in range(warmup):
             step()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
+        ev0, ev1 = GPU.event(), GPU.event()
+        GPU.synchronize()
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        GPU.synchronize()
         t0 = time.perf_counter()
         ev0.record(self.stream)                      # HIP events on the launch stream, around the K timed steps
         for _ in range(steps):
             step()
         ev1.record(self.stream)
-        torch.cuda.synchronize()
+        GPU.synchronize()
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        GPU.synchronize()
         elapsed = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / max(1, steps)      # average launch duration, inter-launch gaps included
         if self.world > 1:
@@ -411,13 +449,13 @@ class Bench:
             want = lambda: oc.mul(oc.ENDO, d["scalars_h"], None, self.table_g)
         for _ in range(max(2, steps // 10)):
             step()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
+        ev0, ev1 = GPU.event(), GPU.event()
+        GPU.synchronize()
         ev0.record(self.stream)
         for _ in range(steps):
             step()
         ev1.record(self.stream)
-        torch.cuda.synchronize()
+        GPU.synchronize()
         ms = ev0.elapsed_time(ev1) / steps
         if not np.array_equal(out.cpu().numpy().view(np.uint64), want()):
             raise SystemExit("PARITY FAILURE: alongside op of %s differs from the C oracle" % workload)
@@ -446,11 +484,11 @@ class Bench:
                 eng.mul_endo_dev(scalars, points, out, n)
             times = []
             for _ in range(reps):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a, b = GPU.event(), GPU.event()
                 a.record(self.stream)
                 eng.mul_endo_dev(scalars, points, out, n)
                 b.record(self.stream)
-                torch.cuda.synchronize()
+                GPU.synchronize()
                 times.append(a.elapsed_time(b))
             rec[str(n)] = round(sorted(times)[len(times) // 2], 4)
         rec["unit"] = "ms per call of MUL_endo(m, P), variable base, n elements"
@@ -498,27 +536,27 @@ class Bench:
                     fn(n)
                 times = []
                 for _ in range(reps):
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a, b = GPU.event(), GPU.event()
                     a.record(self.stream)
                     fn(n)
                     b.record(self.stream)
-                    torch.cuda.synchronize()
+                    GPU.synchronize()
                     times.append(a.elapsed_time(b))
                 row[str(n)] = round(sorted(times)[len(times) // 2], 4)
             rec[name] = row
         # parity of what was just timed, on `big` elements
         ops["MUL_endo mixed 50/50"](big)
-        torch.cuda.synchronize()
+        GPU.synchronize()
         got = out.cpu().numpy().view(np.uint64)
         want = np.where(flags_h[:, None] != 0, oc.mul(oc.ENDO, s_h, p_h), oc.mul(oc.ENDO, s_h, None, self.table_g))
         ok = bool(np.array_equal(got, want))
         ops["keygen: comb of [392]G == DH_endo(m, G)"](big)
-        torch.cuda.synchronize()
+        GPU.synchronize()
         kg, kst = aff.cpu().numpy().view(np.uint64), st.cpu().numpy()
         want_kg, want_st = oc.dh(oc.ENDO, s_h, g_h)
         ok = ok and bool(np.array_equal(kg, want_kg)) and bool(np.array_equal(kst, want_st))
         ops["DH_endo(m, Q)"](big)
-        torch.cuda.synchronize()
+        GPU.synchronize()
         ok = ok and bool(np.array_equal(aff.cpu().numpy().view(np.uint64), want_kg))
         rec["parity_ok"] = ok
         rec["unit"] = "ms per call of n elements (device-resident)"
@@ -533,11 +571,11 @@ class Bench:
         from fourq_amd.dist import gather_rows
         times, full = [], None
         for _ in range(reps):
-            torch.cuda.synchronize()
+            GPU.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
             full = gather_rows(out, n * self.world, dst=0)
-            torch.cuda.synchronize()
+            GPU.synchronize()
             times.append((time.perf_counter() - t0) * 1e3)
         if self.rank == 0:
             assert full.shape[0] == n * self.world
@@ -629,7 +667,7 @@ class Bench:
         import torch
         from fourq_amd import Engine
         if getattr(self, "eng_ct", None) is None:
-            self.eng_ct = Engine(self.dev.index, stream=self.stream.cuda_stream)
+            self.eng_ct = GPU.engine(self.local_rank, self.stream)
             self.eng_ct.ct_select = True
         default, self.eng = self.eng, self.eng_ct
         try:
@@ -640,7 +678,7 @@ class Bench:
         if want_words is not None and not ok:
             raise SystemExit("PARITY FAILURE: constant-time selection mode differs from the C oracle (%s)" % workload)
         del d
-        torch.cuda.empty_cache()
+        GPU.empty_cache()
         return {"ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit": rec["unit"], "steps": steps, "batch_per_gpu": n,
                 "ratio_vs_default": round(rec["ms_per_step"] / default_ms, 3), "parity_ok": ok if want_words is not None else None}
 
@@ -716,7 +754,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if rehearse:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    GPU.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world)
@@ -755,7 +793,7 @@ def main():
             r["alongside"] = b.alongside("cfg3", dw, steps=20)
         configs[w] = r
         del dw
-        torch.cuda.empty_cache()
+        GPU.empty_cache()
         if do_ct:
             ct[w] = b.ct_select_record(w, WORKLOADS[w]["batch"], max(5, WORKLOADS[w]["steps"] // 5), 2, want_w, r["ms_per_step"])
 

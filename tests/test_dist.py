@@ -103,3 +103,31 @@ def test_bench_gpus_n_launches_its_own_ranks_before_touching_a_gpu(monkeypatch, 
     with pytest.raises(SystemExit, match="WORLD_SIZE=3"):
         bench.main()
     assert not seen
+
+
+def test_bench_rank_body_runs_world_2_over_gloo_without_a_gpu(tmp_path):
+    """bench.py's N > 1 branch had only ever executed on the GPU box's one-GPU rehearsal.  Here the unmodified
+    bench.main() runs as two rank processes over gloo with the engine replaced by the C oracle (tests/bench_cpu_rank.py): the
+    barrier-bracketed region, the MAX over ranks, per-rank seeds and gates, parity.all_ranks_ok, gather_ms and ranks_seen."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = ["--gpus", "2", "--batch", "384", "--steps", "2", "--warmup", "1", "--no-configs", "--no-pcie", "--no-alongside", "--no-ct", "--no-cpu-baseline"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_cpu_rank.py")] + argv, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(o[1][-2000:] for o in outs)
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.startswith('{"metric"')]
+    assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith('{"metric"')]      # rank 0 alone speaks
+    line = json.loads(lines0[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["backend"].startswith("gloo")
+    assert line["parity"]["ok"] is True and line["parity"]["all_ranks_ok"] is True and line["parity"]["units"] == 384
+    assert line["gather_ms"] > 0 and line["steps"] == 2
+    # whole-job value: both ranks' units over the slower rank's time
+    assert abs(line["value"] - 2 * 384 * 2 / (line["ms_per_step"] * 2 * 1e-3)) / line["value"] < 0.01
