@@ -17,6 +17,12 @@ _to_bytes = int.to_bytes
 _chain = itertools.chain.from_iterable
 
 
+def _fp_words(x):
+    """One GF(p) value -> (low, high) 64-bit words of its residue in [0, p)."""
+    x = int(x) % P127          # the reference reduces with `% p1271` everywhere (fields.py:29-57)
+    return (x & M64, x >> 64)
+
+
 def _words_from_ints(flat, width):
     """Non-negative Python ints below 2^(8*width) -> uint64 array, little-endian words.  One C-level pass: int.to_bytes mapped over the
     values, one join, one frombuffer (round 3's per-word numpy stores cost 4.5 us per element; this is ~0.1 us per int)."""

@@ -918,6 +918,14 @@ FQ_API int fourq_device_count(int* count) {
     return FOURQ_OK;
 }
 
+// Environment.  ONE product option is read from the environment: FOURQ_CT_SELECT (include/fourq_amd.h).  Everything else that
+// changes which kernels a call takes is a TEST HOOK -- it exists so that the tests, tools/fuzz.py and the A/B probes can reach every
+// route at small sizes -- and is read only when FOURQ_DEBUG_ROUTES=1 is set as well (tools/README.md lists the hooks); a production
+// process cannot be re-routed by a stray variable.
+static const char* route_env(const char* name) {
+    const char* gate = getenv("FOURQ_DEBUG_ROUTES");
+    return (gate && atoi(gate) != 0) ? getenv(name) : nullptr;
+}
 FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
     if (!out) return FOURQ_ERR_INVALID;
     *out = nullptr;
@@ -949,7 +957,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         int occ = 8, o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<ENDO, FUSED, false>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, ladder_kernel<WINDOWED, FUSED, true>, BLOCK, 0) == hipSuccess && o > 0 && o < occ) occ = o;
-        if (const char* env = getenv("FOURQ_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) occ = v; }
+        if (const char* env = route_env("FOURQ_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) occ = v; }
         c->lanes = (size_t)c->cus * occ * BLOCK;
         c->lanes_w4 = (size_t)c->cus * 4 * BLOCK;
         // The two-kernel route (prep_kernel + ladder_kernel<PREBUILT>) for MUL_windowed / DH_* past one fused generation was worth
@@ -957,21 +965,21 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         // 3-6 % ahead at every size and config 4's step 4.7 % faster on it (profiles/r04_routes.txt).  The route stays reachable for
         // experiments (FOURQ_SPLIT_MIN = smallest batch that takes it); mixed batches keep their own use of both kernels.
         c->split_min = ~(size_t)0;
-        if (const char* env = getenv("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
-        if (const char* env = getenv("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
+        if (const char* env = route_env("FOURQ_SPLIT_MIN")) { long v = atol(env); if (v > 0) c->split_min = (size_t)v; }
+        if (const char* env = route_env("FOURQ_SPLIT_ALL")) c->split_all = atoi(env) != 0;
         c->split_endo_min = 0;
-        if (const char* env = getenv("FOURQ_SPLIT_ENDO_MIN")) { long v = atol(env); if (v >= 0) c->split_endo_min = (size_t)v; }
-        if (const char* env = getenv("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
-        if (const char* env = getenv("FOURQ_HOST_ZERO_COPY")) c->host_zero_copy = atoi(env) != 0;
+        if (const char* env = route_env("FOURQ_SPLIT_ENDO_MIN")) { long v = atol(env); if (v >= 0) c->split_endo_min = (size_t)v; }
+        if (const char* env = route_env("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
+        if (const char* env = route_env("FOURQ_HOST_ZERO_COPY")) c->host_zero_copy = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
-        if (const char* env = getenv("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
+        if (const char* env = route_env("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
         c->pair_max = c->lanes / 2;                        // two lanes per element: half a generation fills the chip
-        if (const char* env = getenv("FOURQ_PAIR_MAX")) { long v = atol(env); if (v >= 0 && (size_t)v <= c->lanes / 2) c->pair_max = (size_t)v; }
+        if (const char* env = route_env("FOURQ_PAIR_MAX")) { long v = atol(env); if (v >= 0 && (size_t)v <= c->lanes / 2) c->pair_max = (size_t)v; }
         c->quad_max = c->pair_max < c->lanes / 4 ? c->pair_max : c->lanes / 4;
-        if (const char* env = getenv("FOURQ_QUAD_MAX")) { long v = atol(env); if (v >= 0 && (size_t)v <= c->quad_max) c->quad_max = (size_t)v; }
-        if (const char* env = getenv("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
+        if (const char* env = route_env("FOURQ_QUAD_MAX")) { long v = atol(env); if (v >= 0 && (size_t)v <= c->quad_max) c->quad_max = (size_t)v; }
+        if (const char* env = route_env("FOURQ_NORM_K")) { int v = atoi(env); if (v == 0 || v == 2 || v == 4 || v == 8) c->norm_k = v; }
         c->split_chunk = c->lanes_w4;
-        if (const char* env = getenv("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }
+        if (const char* env = route_env("FOURQ_SPLIT_CHUNK")) { long v = atol(env); if (v >= BLOCK && (size_t)v <= c->lanes_w4) c->split_chunk = (size_t)v; }
         size_t scratch_u32 = c->lanes * NDSlots::SLOT;                                   // fused kernels: N, D per resident lane
         if (c->lanes_w4 * PrebuiltSlots::SLOT > scratch_u32) scratch_u32 = c->lanes_w4 * PrebuiltSlots::SLOT;   // two-kernel route: per element of a round
         if ((size_t)COMB_POINTS * SLOT_U32 > scratch_u32) scratch_u32 = (size_t)COMB_POINTS * SLOT_U32;         // comb_table_kernel: whole entries

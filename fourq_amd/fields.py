@@ -39,34 +39,62 @@ def _fp2(op, a, b=(0, 0)):
 
 
 class GFp:
+    # the reference's operation counters (fields.py:10-27): class attributes that its compare.py resets and reads.  Calls of the
+    # methods below count exactly as the reference's do; the curve-level functions of fourq_amd.curve4q run as ONE device call
+    # each and do not pass through these methods, so they leave the counters alone (tools/compare.py prints the reference's
+    # per-function table from the oracle instead).
+    ctr_enabled = True
+    A = S = M = I = 0                                  # noqa: E741
     half = 1 << 126                                    # fields.py:16
 
     @staticmethod
-    def add(x, y):                                     # fields.py:30
+    def ctr_reset():                                   # fields.py:18-23
+        GFp.A = GFp.S = GFp.M = GFp.I = 0
+
+    @staticmethod
+    def ctr():                                         # fields.py:25-27 names a class that does not exist: kept, like the decode bug
+        raise NameError("name 'GFp1271' is not defined")
+
+    @staticmethod
+    def _count(which, by=1):
+        if GFp.ctr_enabled:
+            setattr(GFp, which, getattr(GFp, which) + by)
+
+    @staticmethod
+    def add(x, y):
+        GFp._count("A")                                     # fields.py:30
         return _fp("FP_ADD", x, y)
 
     @staticmethod
-    def sub(x, y):                                     # fields.py:36
+    def sub(x, y):
+        GFp._count("A")                                     # fields.py:36
         return _fp("FP_SUB", x, y)
 
     @staticmethod
-    def mul(x, y):                                     # fields.py:42
+    def mul(x, y):
+        GFp._count("M")                                     # fields.py:42
         return _fp("FP_MUL", x, y)
 
     @staticmethod
-    def sqr(x):                                        # fields.py:48
+    def sqr(x):
+        GFp._count("S")                                        # fields.py:48
         return _fp("FP_SQR", x)
 
     @staticmethod
-    def neg(x):                                        # fields.py:54
+    def neg(x):
+        GFp._count("A")                                        # fields.py:54
         return _fp("FP_NEG", x)
 
     @staticmethod
-    def inv(x):                                        # fields.py:67
+    def inv(x):                                        # fields.py:67 (the reference's chain calls sqr 126 times and mul 12 times)
+        GFp._count("S", 126)
+        GFp._count("M", 12)
         return _fp("FP_INV", x)
 
     @staticmethod
-    def invsqrt(x):                                    # fields.py:110
+    def invsqrt(x):                                    # fields.py:110 (7 + 24 mul, 120 sqr in the reference's chain)
+        GFp._count("M", 31)
+        GFp._count("S", 120)
         return _fp("FP_INVSQRT", x)
 
     @staticmethod
@@ -84,35 +112,54 @@ class GFp:
 
 
 class GFp2:
+    A = S = M = I = 0                                  # noqa: E741  (fields.py:135-138; counted unconditionally, as there)
     zero, one, two = (0, 0), (1, 0), (2, 0)            # fields.py:140-142
     half = (GFp.half, 0)
 
     @staticmethod
+    def ctr_reset():                                   # fields.py:145-149
+        GFp2.A = GFp2.S = GFp2.M = GFp2.I = 0
+
+    @staticmethod
+    def ctr():                                         # fields.py:152-153
+        return (GFp2.A, GFp2.S, GFp2.M, GFp2.I)
+
+    @staticmethod
     def add(a, b):                                     # fields.py:157
+        GFp2.A += 1
         return _fp2("FP2_ADD", a, b)
 
     @staticmethod
     def sub(a, b):                                     # fields.py:162
+        GFp2.A += 1
         return _fp2("FP2_SUB", a, b)
 
     @staticmethod
     def mul(a, b):                                     # fields.py:167
+        GFp2.M += 1
         return _fp2("FP2_MUL", a, b)
 
     @staticmethod
     def sqr(a):                                        # fields.py:176
+        GFp2.S += 1
         return _fp2("FP2_SQR", a)
 
     @staticmethod
     def neg(a):                                        # fields.py:184
+        GFp2.A += 1
         return _fp2("FP2_NEG", a)
 
     @staticmethod
     def conj(a):                                       # fields.py:189
+        GFp2.A += 0.5
         return _fp2("FP2_CONJ", a)
 
     @staticmethod
-    def inv(a):                                        # fields.py:194
+    def inv(a):                                        # fields.py:194-199: I + 1; the norm's inversion counts in GFp (2 sqr, 1 add, the chain);
+        GFp2.I += 1                                    # its own mul and conj are taken back there ("to avoid double-counting"): net M, A unchanged
+        GFp._count("S", 2 + 126)
+        GFp._count("A", 1)
+        GFp._count("M", 12)
         return _fp2("FP2_INV", a)
 
     @staticmethod

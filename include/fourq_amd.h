@@ -95,7 +95,10 @@ int fourq_ctx_sync(fourq_ctx *ctx);
  * an address -- which is NOT constant-time with respect to the scalar's digits.  ON (this call, or
  * FOURQ_CT_SELECT=1 in the environment when the context is created): every ladder step reads the whole table and
  * keeps the wanted entry by masks; per-lane tables live in registers; signs are applied arithmetically.  Results are
- * bit-identical in both modes; the price of ON is in DESIGN.md section 10. */
+ * bit-identical in both modes; the price of ON is in DESIGN.md section 10.
+ * Environment: FOURQ_CT_SELECT is the ONE variable the library reads as a product option.  The variables that steer batches onto
+ * particular kernels (FOURQ_SPLIT_*, FOURQ_PAIR_MAX, FOURQ_QUAD_MAX, FOURQ_MIXED_QUEUE, FOURQ_NORM_K, FOURQ_BLOCKS_PER_CU,
+ * FOURQ_HOST_BOUNCE, FOURQ_HOST_ZERO_COPY) are test hooks: they are ignored unless FOURQ_DEBUG_ROUTES=1 is set (tools/README.md). */
 int fourq_ctx_set_ct_select(fourq_ctx *ctx, int on);
 int fourq_ctx_get_ct_select(const fourq_ctx *ctx, int *on);
 /* Resident lanes the ladder kernels are launched with (scratch is sized for this many). */

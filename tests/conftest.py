@@ -16,6 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True, scope="session")
+def _route_hooks_enabled():
+    """The tests reach every kernel route at small sizes through the library's test hooks (FOURQ_SPLIT_MIN, FOURQ_PAIR_MAX, ...),
+    which the library reads only under FOURQ_DEBUG_ROUTES=1 (fourq_amd/csrc/fourq_amd.hip, tools/README.md)."""
+    os.environ["FOURQ_DEBUG_ROUTES"] = "1"
+    yield
+
+
 def unhex(v):
     """Inverse of make_golden.hx: hex strings -> ints, lists -> tuples (recursively)."""
     if isinstance(v, bool):

@@ -181,3 +181,28 @@ def test_reference_shaped_field_namespaces():
         assert GFp2.invsqrt((x, 0)) == o.GFp2.invsqrt((x, 0))
         assert GFp.select(1, x, y) == x and GFp2.select(0, a, b) == b
     assert (GFp2.zero, GFp2.one, GFp2.two, GFp.half) == ((0, 0), (1, 0), (2, 0), 1 << 126)
+
+
+@pytest.mark.gpu
+def test_field_operation_counters_of_the_reference():
+    """GFp / GFp2 carry the reference's counters A, S, M, I with ctr() / ctr_reset() (fields.py:10-27, :135-154): every method counts as
+    the reference's does (conj half an addition, GFp2.inv one I and nothing else in GFp2, its norm's chain in GFp), and GFp.ctr()
+    raises the reference's own NameError (it names a class `GFp1271` that does not exist)."""
+    from fourq_amd.fields import GFp, GFp2
+    a, b = (3, 5), (7, 11)
+    GFp2.ctr_reset(); GFp.ctr_reset()
+    GFp2.mul(GFp2.add(a, b), GFp2.sub(a, b)); GFp2.sqr(a); GFp2.neg(b); GFp2.conj(a)
+    assert GFp2.ctr() == (3.5, 1, 1, 0)
+    assert GFp2.mul(GFp2.inv(a), a) == (1, 0)
+    assert GFp2.ctr() == (3.5, 1, 2, 1) and (GFp.A, GFp.S, GFp.M, GFp.I) == (1, 128, 12, 0)
+    GFp.ctr_enabled = False
+    try:
+        assert GFp.mul(GFp.inv(9), 9) == 1 and (GFp.A, GFp.S, GFp.M) == (1, 128, 12)
+    finally:
+        GFp.ctr_enabled = True
+    GFp.add(1, 2); GFp.sub(1, 2); GFp.neg(1); GFp.sqr(3); GFp.mul(3, 4)
+    assert (GFp.A, GFp.S, GFp.M) == (4, 129, 13)
+    with pytest.raises(NameError, match="GFp1271"):
+        GFp.ctr()
+    GFp2.ctr_reset(); GFp.ctr_reset()
+    assert GFp2.ctr() == (0, 0, 0, 0)

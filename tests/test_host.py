@@ -65,6 +65,27 @@ def test_every_included_file_is_a_tracked_dependency_of_the_build():
     assert os.path.exists(build.PLACE_TOOL) and build.is_stale() in (True, False)
 
 
+def test_every_environment_variable_the_library_reads_is_documented():
+    """every FOURQ_* string in the built library is either the one product option the header documents or a test
+    hook behind the FOURQ_DEBUG_ROUTES gate that tools/README.md lists (and route_env() is the only reader of those)."""
+    import re
+    from fourq_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    in_lib = {m.decode() for m in re.findall(rb"FOURQ_[A-Z][A-Z0-9_]+", blob)}
+    header = open(os.path.join(ROOT, "include", "fourq_amd.h")).read()
+    readme = open(os.path.join(ROOT, "tools", "README.md")).read()
+    hooks = {"FOURQ_BLOCKS_PER_CU", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_PAIR_MAX",
+             "FOURQ_QUAD_MAX", "FOURQ_MIXED_QUEUE", "FOURQ_NORM_K", "FOURQ_HOST_BOUNCE", "FOURQ_HOST_ZERO_COPY"}
+    env_like = {v for v in in_lib if not v.startswith(("FOURQ_ERR", "FOURQ_OK", "FOURQ_DH_", "FOURQ_DECODE", "FOURQ_FP", "FOURQ_PT", "FOURQ_MAX", "FOURQ_TABLE", "FOURQ_COMB_", "FOURQ_R"))}
+    assert env_like == hooks | {"FOURQ_CT_SELECT", "FOURQ_DEBUG_ROUTES"}, sorted(env_like ^ (hooks | {"FOURQ_CT_SELECT", "FOURQ_DEBUG_ROUTES"}))
+    assert "FOURQ_CT_SELECT" in header and "FOURQ_DEBUG_ROUTES" in header
+    for v in hooks | {"FOURQ_CT_SELECT", "FOURQ_DEBUG_ROUTES"}:
+        assert v in readme, v
+    src = open(os.path.join(ROOT, "fourq_amd", "csrc", "fourq_amd.hip")).read()
+    for v in hooks:
+        assert 'route_env("%s")' % v in src and 'getenv("%s")' % v not in src, v
+
+
 def test_tuple_codec_is_fast_enough_to_be_worth_swapping_in():
     """the tuple-level API spent 4.5 + 5.6 us per element packing and unpacking in Python loops.  With
     csrc/fastcodec.c (built in-tree by build()) an R1 point + scalar packs and an R1 point unpacks in well under a microsecond on this

@@ -3,6 +3,7 @@
 boundary, random routing knobs, rejected points sprinkled in.  Test infrastructure (uses oracle/); GPU box.
     python tools/fuzz.py [seconds]"""
 import os
+os.environ.setdefault("FOURQ_DEBUG_ROUTES", "1")      # the FOURQ_* route hooks below are read only under this gate (tools/README.md)
 import random
 import sys
 import time

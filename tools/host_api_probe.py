@@ -3,6 +3,7 @@
 pinned caller arrays, pageable arrays through the bounce slots, pageable arrays handed to hipMemcpyAsync directly
 (FOURQ_HOST_BOUNCE=0).  Outputs are preallocated so that first-touch page faults are not part of the figure."""
 import os, sys, time
+os.environ.setdefault("FOURQ_DEBUG_ROUTES", "1")      # the FOURQ_* route hooks below are read only under this gate (tools/README.md)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bench import seeded_scalars

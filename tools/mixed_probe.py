@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("FOURQ_DEBUG_ROUTES", "1")      # the FOURQ_* route hooks below are read only under this gate (tools/README.md)
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from bench import seeded_scalars

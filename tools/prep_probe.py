@@ -2,6 +2,7 @@
 """Runs MUL_endo through prep_kernel + ladder_kernel<PREBUILT> at 2^16 (FOURQ_SPLIT_ALL) a few times: a target for
 rocprofv3 --pmc when the table construction and the ladder are to be looked at separately (GPU box)."""
 import os
+os.environ.setdefault("FOURQ_DEBUG_ROUTES", "1")      # the FOURQ_* route hooks below are read only under this gate (tools/README.md)
 import sys
 
 os.environ["FOURQ_SPLIT_ALL"] = "1"

@@ -2,6 +2,7 @@
 """Kernel time of small variable-base and fixed-base batches with one, two and four lanes per element (GPU box).
     python tools/quad_probe.py        -> table, ms per call (device-resident, HIP events, best of 7)"""
 import os, subprocess, sys
+os.environ.setdefault("FOURQ_DEBUG_ROUTES", "1")      # the FOURQ_* route hooks below are read only under this gate (tools/README.md)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 

@@ -2,6 +2,7 @@
 """Fused launch vs prep + ladder for variable-base MUL_endo at batch sizes that do not fill whole generations
 of resident lanes (GPU box).   python tools/route_probe.py [n ...]"""
 import os
+os.environ.setdefault("FOURQ_DEBUG_ROUTES", "1")      # the FOURQ_* route hooks below are read only under this gate (tools/README.md)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

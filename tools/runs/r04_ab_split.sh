@@ -1,5 +1,6 @@
 # same-box: the fused route (asm ladder bodies) against the two-kernel route for DH batches (cfg4) and large MUL_windowed / DH batches
 mkdir -p gpurun_out/r04b
+export FOURQ_DEBUG_ROUTES=1      # FOURQ_SPLIT_MIN below is a test hook
 for rep in 1 2; do
   for mode in default nosplit; do
     if [ $mode = nosplit ]; then export FOURQ_SPLIT_MIN=1000000000; else unset FOURQ_SPLIT_MIN; fi
