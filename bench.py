@@ -271,15 +271,15 @@ class _Cuda:
 
     def synchronize(self):
         import torch
-        GPU.synchronize()
+        torch.cuda.synchronize()
 
     def event(self):
         import torch
-        return GPU.event()
+        return torch.cuda.Event(enable_timing=True)
 
     def empty_cache(self):
         import torch
-        GPU.empty_cache()
+        torch.cuda.empty_cache()
 
     def engine(self, index, stream):
         from fourq_amd import Engine
