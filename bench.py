@@ -653,6 +653,56 @@ class Bench:
                 rec["pageable_caller"] = r
             else:
                 rec[label.split(" ")[0]] = dict(r, call=label)
+        if workload == "cfg2":
+            # the same operation through the I/O formats that do not waste the link (SURVEY.md 8(d) "affine-only I/O variant"): the same
+            # points in affine form / encoded, canonical affine / encoded results; expected words from the C oracle (R1toAffine, encode
+            # of its R1 rows -- the affine result of a scalar multiplication does not depend on the input's projective representative)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_c as oc
+            aff_in = oc.r1_to_affine(d["points_h"])
+            want_aff = oc.r1_to_affine(want_words)
+            want_enc = oc.encode(want_aff)
+            a_pin, e_pin = pin(aff_in), pin(oc.encode(aff_in))
+            oa_pin, oe_pin, st_pin = pin_empty((n, 8)), pin_empty((n, 32), np.uint8), pin_empty((n,), np.uint8)
+
+            def mul_bytes():
+                out, status = eng.mul_bytes(s_pin, e_pin, out=oe_pin, status=st_pin)
+                if status.any():
+                    raise SystemExit("cfg2 bytes flavour: a point did not decode")
+                return out
+            variants = {"affine": (lambda: eng.mul_affine(s_pin, a_pin, out=oa_pin), want_aff, 96, 64,
+                                   "fourq_mul_endo_affine_batch: scalar + affine point in, canonical affine out (parity level L1)"),
+                        "bytes": (mul_bytes, want_enc, 64, 33, "fourq_mul_endo_bytes_batch: scalar + 32-byte point in, 32-byte point + status out")}
+            for label, (call, want_v, b_in, b_out, what) in variants.items():
+                call()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    got = call()
+                dt = (time.perf_counter() - t0) / reps
+                if not np.array_equal(got, want_v):
+                    raise SystemExit("PARITY FAILURE: host-array path (cfg2, %s I/O) differs from the C oracle" % label)
+                st = eng.host_stats()
+                rec[label] = {"call": what, "io": "%d B in + %d B out per unit" % (b_in, b_out), "value": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                              "chunks": st["chunks"], "wall_gbs_both_directions": round(n * (b_in + b_out) / dt / 1e9, 2)}
+            # One generation is one chunk: copy in, kernels, copy out in series, whatever the format.  Sixteen generations (the same
+            # elements sixteen times over, 2^20) is where the pipeline overlaps them and the format decides: R1 I/O is bound by the link.
+            reps_big, big = 3, 16 * n
+            sb, pb, ab, eb = (pin(np.tile(x, (16, 1))) for x in (d["scalars_h"], d["points_h"], aff_in, oc.encode(aff_in)))
+            ob, oab, oeb, stb = pin_empty((big, 20)), pin_empty((big, 8)), pin_empty((big, 32), np.uint8), pin_empty((big,), np.uint8)
+            big_calls = {"r1": (lambda: eng.mul_endo(sb, pb, out=ob), want_words, 352),
+                         "affine": (lambda: eng.mul_affine(sb, ab, out=oab), want_aff, 160),
+                         "bytes": (lambda: eng.mul_bytes(sb, eb, out=oeb, status=stb)[0], want_enc, 97)}
+            rec["at_2^20"] = {"batch": big, "reps": reps_big}
+            for label, (call, want_v, nbytes) in big_calls.items():
+                call()
+                t0 = time.perf_counter()
+                for _ in range(reps_big):
+                    got = call()
+                dt = (time.perf_counter() - t0) / reps_big
+                if not all(np.array_equal(got[k * n:(k + 1) * n], want_v) for k in range(16)):
+                    raise SystemExit("PARITY FAILURE: host-array path (cfg2 x 16, %s I/O) differs from the C oracle" % label)
+                rec["at_2^20"][label] = {"value": round(big / dt, 1), "ms_per_step": round(dt * 1e3, 3), "chunks": eng.host_stats()["chunks"],
+                                         "wall_gbs_both_directions": round(big * nbytes / dt / 1e9, 2)}
         rec["note"] = ("value = units / wall-clock of the synchronous host-array call (H2D, kernels, D2H pipelined over chunks of whole "
                        "kernel generations); gbs_* = bytes / summed copy durations (HIP events on the copy streams), i.e. the link rate while a "
                        "copy is running; every output compared with the C oracle")

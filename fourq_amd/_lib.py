@@ -12,7 +12,7 @@ DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
 DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3
 
 MAX_BATCH = 0xFFFFFF00
-ABI_VERSION = 300                    # fourq_version(): 0.3.0 (round 3: fourq_device_count, fourq_build_id, fourq_ctx_reserve)
+ABI_VERSION = 400                    # fourq_version(): 0.4.0 (round 4: fourq_mul_*_affine_batch, fourq_mul_*_bytes_batch)
 COMB_POINTS = 1024 + 80              # FOURQ_COMB_POINTS: the fast comb and the one the constant-time mode scans
 COMB_WORDS = COMB_POINTS * 12        # FOURQ_COMB_WORDS
 BYTES_DECODE_BASE = 16
@@ -55,6 +55,14 @@ PROTOTYPES = {
     "fourq_mul_windowed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_mul_endo_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_mul_windowed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_affine_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_affine_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_affine_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_affine_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_bytes_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_bytes_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_endo_bytes_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "fourq_mul_windowed_bytes_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_mul_endo_fixed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_mul_windowed_fixed_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "fourq_mul_endo_fixed_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),

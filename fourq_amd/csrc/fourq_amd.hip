@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void encode_status_kernel(const u64* affine,
                                                               u64* out, uint8_t* status, u32 n) {
     u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    const uint8_t sd = st_decode[i], sh = st_dh[i];
+    const uint8_t sd = st_decode[i], sh = st_dh ? st_dh[i] : 0;        // st_dh == NULL: a stage that cannot fail (MUL_*)
     const uint8_t st = sd ? (uint8_t)(16 + sd) : sh;
     u64 w[4];
     point_encode(load_fe2(affine + 8 * (size_t)i), load_fe2(affine + 8 * (size_t)i + 4), w);
@@ -191,6 +191,31 @@ __global__ __launch_bounds__(BLOCK) void broadcast_point_kernel(AffineArg point,
     uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)i);
 #pragma unroll
     for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)point.w[2 * k], (u32)(point.w[2 * k] >> 32), (u32)point.w[2 * k + 1], (u32)(point.w[2 * k + 1] >> 32));
+}
+// MUL_* with affine I/O ("affine-only I/O variant"): AffineToR1 in front (curve4q.py:100-101), R1toAffine behind
+// (curve4q.py:103-106, one GFp2.inv per element: ~2 % of a MUL_endo's multiply-adds).  The R1 rows in between stay on the device.
+__global__ __launch_bounds__(BLOCK) void lift_affine_kernel(const u64* affine, u64* r1, u32 n) {
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint4* src = reinterpret_cast<const uint4*>(affine + 8 * (size_t)i);
+    uint4* dst = reinterpret_cast<uint4*>(r1 + 20 * (size_t)i);
+    const uint4 x0 = src[0], x1 = src[1], y0 = src[2], y1 = src[3];
+    dst[0] = x0; dst[1] = x1; dst[2] = y0; dst[3] = y1;                                  // X, Y
+    dst[4] = make_uint4(1, 0, 0, 0); dst[5] = make_uint4(0, 0, 0, 0);                   // Z = 1
+    dst[6] = x0; dst[7] = x1; dst[8] = y0; dst[9] = y1;                                  // Ta = X, Tb = Y
+}
+__global__ __launch_bounds__(BLOCK) void lower_r1_kernel(const u64* r1, u64* affine, u32 n) {
+    u32 i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    R1 q;
+    q.X = load_fe2(r1 + 20 * (size_t)i); q.Y = load_fe2(r1 + 20 * (size_t)i + 4); q.Z = load_fe2(r1 + 20 * (size_t)i + 8);
+    Fe2<1> ax, ay;
+    r1_to_affine(q, ax, ay);
+    u64 o[8];
+    store_fe2(o, ax); store_fe2(o + 4, ay);
+    uint4* dst = reinterpret_cast<uint4*>(affine + 8 * (size_t)i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
 }
 // status of a two-stage exchange: the first failure of either half (the second half already zeroed its output)
 __global__ __launch_bounds__(BLOCK) void merge_status_kernel(const uint8_t* first, uint8_t* status, u32 n) {
@@ -686,6 +711,7 @@ int ensure_work(fourq_ctx* c, size_t bytes) { return grow(c, &c->work, &c->work_
 // intermediates of the protocol-level calls for n elements (decoded keys / first-half results, their status bytes)
 size_t dh_bytes_work_bytes(size_t n) { return 2 * n * 64 + 2 * align256(n); }
 size_t exchange_work_bytes(size_t n) { return 2 * n * 64 + align256(n); }
+size_t mul_affine_work_bytes(size_t n) { return 2 * n * 160 + n * 64 + align256(n); }      // R1 in, R1 out, decoded points, decode status
 
 using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev, size_t m)>;
 
@@ -887,7 +913,7 @@ extern "C" {
 
 #define FQ_API __attribute__((visibility("default")))
 
-FQ_API int fourq_version(void) { return 300; }    // 0.3.0; fourq_amd/_lib.py checks it at load time
+FQ_API int fourq_version(void) { return 400; }    // 0.4.0; fourq_amd/_lib.py checks it at load time
 #ifndef FQ_BUILD_ID
 #define FQ_BUILD_ID "unknown"
 #endif
@@ -1074,8 +1100,10 @@ FQ_API int fourq_ctx_reserve(fourq_ctx* c, size_t n) {
     CtxGuard g(c);
     int rc = ensure_proj(c, n);
     if (rc) return rc;
-    const size_t a = dh_bytes_work_bytes(n), b = exchange_work_bytes(n);
-    return ensure_work(c, a > b ? a : b);
+    size_t need = dh_bytes_work_bytes(n);
+    if (exchange_work_bytes(n) > need) need = exchange_work_bytes(n);
+    if (mul_affine_work_bytes(n) > need) need = mul_affine_work_bytes(n);
+    return ensure_work(c, need);
 }
 FQ_API int fourq_ctx_lanes(const fourq_ctx* c, size_t* lanes) {
     if (!c || !lanes) return FOURQ_ERR_INVALID;
@@ -1390,6 +1418,72 @@ static int dh_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const 
         return dh_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], table, (uint8_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
+// ---- MUL_* with affine / encoded I/O: R1toAffine(MUL_<algo>(m, AffineToR1(P))) and encode(.) of it --------------------------
+// 160 (96) bytes per operation across the ABI instead of the raw-R1 form's 352: the host-array calls are bound by the link, not by the
+// kernels ("PCIe-inclusive").  Parity level L1 (canonical affine); the raw-R1 entry points are untouched.
+static int mul_affine_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points_affine, uint64_t* out_affine, size_t n) {
+    if (!c || !scalars || !points_affine || !out_affine || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!aligned16(scalars) || !aligned16(points_affine) || !aligned16(out_affine)) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    CtxGuard g(c);
+    int rc = ensure_work(c, mul_affine_work_bytes(n));
+    if (rc) return rc;
+    uint64_t* r1_in = (uint64_t*)c->work;
+    uint64_t* r1_out = (uint64_t*)(c->work + n * 160);
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(lift_affine_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, points_affine, r1_in, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    if ((rc = mul_dev(c, algo, scalars, r1_in, nullptr, r1_out, nullptr, n))) return rc;
+    hipLaunchKernelGGL(lower_r1_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, r1_out, out_affine, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+static int mul_affine_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points_affine, uint64_t* out_affine, size_t n) {
+    if (!c || !scalars || !points_affine || !out_affine || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    CtxGuard g(c);
+    PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points_affine, nullptr, 64 } };
+    PipeArray o[1] = { { nullptr, (char*)out_affine, 64 } };
+    return run_pipeline(c, in, 2, o, 1, n, pipe_chunk(c, true), [&](char* const* di, char* const* dout, size_t m) {
+        return mul_affine_dev(c, algo, (const uint64_t*)di[0], (const uint64_t*)di[1], (uint64_t*)dout[0], m);
+    });
+}
+// decode -> MUL_<algo> -> encode.  status: 0 ok | 16 + FOURQ_DECODE_* (out32 is zero then); MUL_* itself cannot fail.
+static int mul_bytes_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint8_t* points32, uint8_t* out32, uint8_t* status, size_t n) {
+    if (!c || !scalars || !points32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (!aligned16(scalars) || !aligned16(points32) || !aligned16(out32)) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    CtxGuard g(c);
+    int rc = ensure_work(c, mul_affine_work_bytes(n));
+    if (rc) return rc;
+    uint64_t* pts = (uint64_t*)(c->work + 2 * n * 160);        // decoded points, then the affine results (mul_affine_dev owns the first 320 n bytes)
+    uint8_t* st_decode = (uint8_t*)(c->work + 2 * n * 160 + n * 64);
+    if ((rc = fourq_decode_batch_dev(c, points32, pts, st_decode, n))) return rc;
+    if ((rc = mul_affine_dev(c, algo, scalars, pts, pts, n))) return rc;             // in place: every element is read before it is written
+    hipLaunchKernelGGL(encode_status_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, pts, st_decode, (const uint8_t*)nullptr,
+                       (u64*)out32, status, (u32)n);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+static int mul_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint8_t* points32, uint8_t* out32, uint8_t* status, size_t n) {
+    if (!c || !scalars || !points32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
+    if (n == 0) return FOURQ_OK;
+    CtxGuard g(c);
+    PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points32, nullptr, 32 } };
+    PipeArray o[2] = { { nullptr, (char*)out32, 32 }, { nullptr, (char*)status, 1 } };
+    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, true), [&](char* const* di, char* const* dout, size_t m) {
+        return mul_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], (uint8_t*)dout[0], (uint8_t*)dout[1], m);
+    });
+}
+FQ_API int fourq_mul_endo_affine_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) { return mul_affine_dev(c, ENDO, s, p, o, n); }
+FQ_API int fourq_mul_windowed_affine_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) { return mul_affine_dev(c, WINDOWED, s, p, o, n); }
+FQ_API int fourq_mul_endo_affine_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) { return mul_affine_host(c, ENDO, s, p, o, n); }
+FQ_API int fourq_mul_windowed_affine_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) { return mul_affine_host(c, WINDOWED, s, p, o, n); }
+FQ_API int fourq_mul_endo_bytes_batch_dev(fourq_ctx* c, const uint64_t* s, const uint8_t* p, uint8_t* o, uint8_t* st, size_t n) { return mul_bytes_dev(c, ENDO, s, p, o, st, n); }
+FQ_API int fourq_mul_windowed_bytes_batch_dev(fourq_ctx* c, const uint64_t* s, const uint8_t* p, uint8_t* o, uint8_t* st, size_t n) { return mul_bytes_dev(c, WINDOWED, s, p, o, st, n); }
+FQ_API int fourq_mul_endo_bytes_batch(fourq_ctx* c, const uint64_t* s, const uint8_t* p, uint8_t* o, uint8_t* st, size_t n) { return mul_bytes_host(c, ENDO, s, p, o, st, n); }
+FQ_API int fourq_mul_windowed_bytes_batch(fourq_ctx* c, const uint64_t* s, const uint8_t* p, uint8_t* o, uint8_t* st, size_t n) { return mul_bytes_host(c, WINDOWED, s, p, o, st, n); }
+
 FQ_API int fourq_dh_endo_bytes_batch_dev(fourq_ctx* c, const uint64_t* s, const uint8_t* k, const uint64_t* t, uint8_t* o, uint8_t* st, size_t n) {
     return dh_bytes_dev(c, ENDO, s, k, t, o, st, n);
 }

@@ -187,6 +187,36 @@ class Engine:
     def mul_windowed(self, scalars, points_r1, out=None):
         return self._mul(self._lib.fourq_mul_windowed_batch, scalars, points_r1, 20, out)
 
+    def mul_affine(self, scalars, points_affine, kind="endo", out=None):
+        """R1toAffine(MUL_<kind>(m_i, AffineToR1(P_i))) (curve4q.py:100-106): affine in, canonical affine out -- 160 bytes per
+        operation across the link instead of the raw-R1 form's 352 (fourq_mul_*_affine_batch)."""
+        s, p = _host(scalars, 4), _host(points_affine, 8)
+        if len(s) != len(p):
+            raise ValueError("scalars and points differ in length")
+        out = _out(out, len(s), 8)
+        fn = self._lib.fourq_mul_endo_affine_batch if kind == "endo" else self._lib.fourq_mul_windowed_affine_batch
+        self._ck(fn(self._ctx, _ptr(s), _ptr(p), _ptr(out), len(s)))
+        return out
+
+    def mul_bytes(self, scalars, points32, kind="endo", out=None, status=None):
+        """encode(R1toAffine(MUL_<kind>(m_i, AffineToR1(decode(B_i))))) (curve4q.py:41-96): 32-byte points in and out, 96 bytes per
+        operation (fourq_mul_*_bytes_batch).  Returns ((n, 32) uint8, status): 0 ok, 16 + decode status."""
+        s, b = _host(scalars, 4), _host(points32, 32, np.uint8)
+        if len(s) != len(b):
+            raise ValueError("scalars and points differ in length")
+        out, status = _out(out, len(s), 32, np.uint8), _out(status, len(s), None, np.uint8)
+        fn = self._lib.fourq_mul_endo_bytes_batch if kind == "endo" else self._lib.fourq_mul_windowed_bytes_batch
+        self._ck(fn(self._ctx, _ptr(s), _ptr(b), _ptr(out), _ptr(status), len(s)))
+        return out, status
+
+    def mul_affine_dev(self, scalars, points_affine, out_affine, n, kind="endo"):
+        fn = self._lib.fourq_mul_endo_affine_batch_dev if kind == "endo" else self._lib.fourq_mul_windowed_affine_batch_dev
+        self._ck(fn(self._ctx, _ptr(scalars), _ptr(points_affine), _ptr(out_affine), n))
+
+    def mul_bytes_dev(self, scalars, points32, out32, status, n, kind="endo"):
+        fn = self._lib.fourq_mul_endo_bytes_batch_dev if kind == "endo" else self._lib.fourq_mul_windowed_bytes_batch_dev
+        self._ck(fn(self._ctx, _ptr(scalars), _ptr(points32), _ptr(out32), _ptr(status), n))
+
     def mul_endo_fixed(self, scalars, table, out=None):
         return self._mul(self._lib.fourq_mul_endo_fixed_batch, scalars, table, None, out)
 

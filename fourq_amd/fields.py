@@ -42,7 +42,7 @@ class GFp:
     # the reference's operation counters (fields.py:10-27): class attributes that its compare.py resets and reads.  Calls of the
     # methods below count exactly as the reference's do; the curve-level functions of fourq_amd.curve4q run as ONE device call
     # each and do not pass through these methods, so they leave the counters alone (tools/compare.py prints the reference's
-    # per-function table from the oracle instead).
+    # per-function table from its own CPU restatement instead).
     ctr_enabled = True
     A = S = M = I = 0                                  # noqa: E741
     half = 1 << 126                                    # fields.py:16

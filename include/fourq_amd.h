@@ -59,6 +59,7 @@ extern "C" {
 
 /* largest batch any entry point accepts (the kernels' 32-bit element counters round n up to whole 256-lane blocks) */
 #define FOURQ_MAX_BATCH 0xffffff00u
+#define FOURQ_BYTES_DECODE_BASE 16  /* status of the *_bytes_* calls: this + FOURQ_DECODE_* when an encoded point does not decode */
 
 #define FOURQ_SCALAR_WORDS 4
 #define FOURQ_AFFINE_WORDS 8
@@ -148,6 +149,21 @@ int fourq_mul_windowed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint
 int fourq_mul_endo_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, uint64_t *out_r1, size_t n);
 int fourq_mul_windowed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_r1, uint64_t *out_r1, size_t n);
 
+/* ---- the same with affine / encoded I/O ("affine-only I/O variant") ----------------
+ * out_affine[i] = R1toAffine(MUL_<algo>(m_i, AffineToR1(x_i, y_i)))   curve4q.py:100-106; canonical affine, n x 8 words: 160 bytes per
+ * operation across the ABI instead of 352.  Like MUL_* itself these check nothing: a point outside the prime-order subgroup gives the
+ * reference's (meaningless) answer (draft-ladd-cfrg-4q.md:467-468). */
+int fourq_mul_endo_affine_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, uint64_t *out_affine, size_t n);
+int fourq_mul_windowed_affine_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, uint64_t *out_affine, size_t n);
+int fourq_mul_endo_affine_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, uint64_t *out_affine, size_t n);
+int fourq_mul_windowed_affine_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *points_affine, uint64_t *out_affine, size_t n);
+/* out32[i] = encode(R1toAffine(MUL_<algo>(m_i, AffineToR1(decode(points32[i])))))   curve4q.py:41-96: 96 bytes per operation.
+ * status[i]: 0 ok; FOURQ_BYTES_DECODE_BASE + FOURQ_DECODE_* when points32[i] does not decode (out32[i] is all zero then). */
+int fourq_mul_endo_bytes_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *points32, uint8_t *out32, uint8_t *status, size_t n);
+int fourq_mul_windowed_bytes_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *points32, uint8_t *out32, uint8_t *status, size_t n);
+int fourq_mul_endo_bytes_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *points32, uint8_t *out32, uint8_t *status, size_t n);
+int fourq_mul_windowed_bytes_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *points32, uint8_t *out32, uint8_t *status, size_t n);
+
 /* ---- fixed-base scalar multiplication: MUL_*(m_i, P, table=T) --------------------------------- */
 /* `table` is 128 words (host pointer in both flavours: it is 1 KiB and is staged once per call) */
 int fourq_mul_endo_fixed_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint64_t *table, uint64_t *out_r1, size_t n);
@@ -182,7 +198,6 @@ int fourq_dh_windowed_batch_dev(fourq_ctx *ctx, const uint64_t *scalars, const u
  * curve4q.py:49-96 (decode), :446-462 (DH_core), :41-46 (encode).  Decoded points and shared points never leave the
  * GPU.  status[i]: 0 ok; FOURQ_DH_NOT_ON_CURVE / FOURQ_DH_NEUTRAL from the DH stage; 16 + FOURQ_DECODE_* when the
  * key does not decode (takes precedence).  out32[i] is all zero unless status[i] == 0. */
-#define FOURQ_BYTES_DECODE_BASE 16
 int fourq_dh_endo_bytes_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *keys32, const uint64_t *table,
                               uint8_t *out32, uint8_t *status, size_t n);
 int fourq_dh_windowed_bytes_batch(fourq_ctx *ctx, const uint64_t *scalars, const uint8_t *keys32, const uint64_t *table,

@@ -410,6 +410,16 @@ EXPORT void fqo_dh_batch(int kind, const u64 *scalars, const u64 *points_affine,
         status[i] = 0;
     }
 }
+/* R1toAffine (curve4q.py:103-106) of every row: (X/Z, Y/Z), canonical. */
+EXPORT void fqo_r1_to_affine_batch(const u64 *points_r1, u64 *out_affine, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) {
+        r1_t q; load_r1(points_r1 + 20 * i, &q);
+        fp2 zi = f2_inv(q.Z);
+        fp2 ax = f2_mul(q.X, zi), ay = f2_mul(q.Y, zi);
+        memcpy(out_affine + 8 * i, &ax, sizeof ax); memcpy(out_affine + 8 * i + 4, &ay, sizeof ay);
+    }
+}
 EXPORT void fqo_decompose_batch(const u64 *scalars, u64 *out, size_t n) {
     for (size_t i = 0; i < n; i++) decompose(scalars + 4 * i, out + 4 * i);
 }

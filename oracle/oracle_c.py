@@ -31,6 +31,8 @@ def lib():
         _lib.fqo_mul_batch.argtypes = [i, vp, vp, vp, vp, sz]
         _lib.fqo_dh_batch.argtypes = [i, vp, vp, vp, vp, vp, sz]
         _lib.fqo_decompose_batch.argtypes = [vp, vp, sz]
+        _lib.fqo_r1_to_affine_batch.argtypes = [vp, vp, sz]
+        _lib.fqo_r1_to_affine_batch.restype = None
         _lib.fqo_num_threads.restype = ctypes.c_int
         _lib.fqo_set_num_threads.argtypes = [i]
         _lib.fqo_set_num_threads.restype = None
@@ -74,6 +76,24 @@ def dh(kind, scalars, points_affine, table_words=None):
     status = np.empty(len(s), dtype=np.uint8)
     lib().fqo_dh_batch(kind, _p(s), _p(pts), _p(tb), _p(out), _p(status), len(s))
     return out, status
+
+
+def r1_to_affine(points_r1):
+    """R1toAffine (curve4q.py:103-106) of every row -> (n, 8) canonical affine words."""
+    pts = _u64(points_r1, 20)
+    out = np.empty((len(pts), 8), dtype=np.uint64)
+    lib().fqo_r1_to_affine_batch(_p(pts), _p(out), len(pts))
+    return out
+
+
+def encode(points_affine):
+    """encode (curve4q.py:41-46) of canonical affine rows -> (n, 32) uint8: y little-endian, top bit = sign(x) (:33-39)."""
+    a = _u64(points_affine, 8)
+    words = a[:, 4:8].copy()
+    x0_zero = (a[:, 0] | a[:, 1]) == 0
+    sign = np.where(x0_zero, a[:, 3] >> np.uint64(62), a[:, 1] >> np.uint64(62)) & np.uint64(1)
+    words[:, 3] |= sign << np.uint64(63)
+    return words.view(np.uint8).reshape(-1, 32)
 
 
 def decompose(scalars):

@@ -62,7 +62,7 @@ def test_default_line_has_the_contract_keys():
     assert v4["algorithmic_mads_per_unit_of_the_algorithm_run"] < v4["algorithmic_mads_per_unit"]
     assert v4["algorithmic_frac_of_the_algorithm_run"] < v4["algorithmic_frac"]
     lib = line["config"]["library"]
-    assert lib["version"] == 300 and len(lib["build_id"]) == 16
+    assert lib["version"] == 400 and len(lib["build_id"]) == 16
     src = r["traffic_source"]
     assert src["loaded_library_build_id"] == lib["build_id"]
     assert (r["traffic"] is None) == (src.get("profiled_library_build_id") != lib["build_id"])      # a figure only for the build it was measured on

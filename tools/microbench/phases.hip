@@ -4,7 +4,7 @@
 //   0  the kernel as shipped (N, D gathered from the lane's HBM slot, E, F from LDS)
 //   1  the ladder gathers ALWAYS entry 0 (same instruction stream, all of a lane's gathers hit one address)
 //   2  no table construction (slots pre-filled by variant 0's previous launch): ladder only
-//   3  table construction as prep_kernel would do it with the LDS scheme: whole packed entries to the slot (FULL)
+// Round 4: build it through the placement pass too (python: fourq_amd.build.compile_unit(path, obj, flags, place=True), then hipcc obj -o exe).
 // Diagnostic build, never part of the product:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -o phases phases.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -29,8 +29,7 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     R1 P = load_r1(points + 20 * (size_t)id);
     u32* slot = scratch + (size_t)id * NDSlots::SLOT;
     uint64_t t1 = stamp();
-    if (VARIANT == 3) build_table_endo_lds<PackedSlots, LdsEF, true>(P, scratch + (size_t)id * PackedSlots::SLOT, ef);
-    else if (VARIANT != 2) build_table_endo_lds<NDSlots>(P, slot, ef);
+    if (VARIANT != 2) build_table_endo_lds<NDSlots>(P, slot, ef);
     else { for (int kk = 0; kk < 8; kk++) { R2 t = r1_to_r2(P); ef.put(kk, t); } }      // LDS filled, HBM slot left from the previous launch
     uint64_t t2 = stamp();
     u64 v[4];
@@ -38,7 +37,7 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     EndoDigits e = recode(v);
     if (VARIANT == 1) { e.d[0] = e.d[1] = e.d[2] = 0; e.top = 0; }
     uint64_t t3 = stamp();
-    R1 Q = ladder_endo<LADDER_CH, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);
+    R1 Q = ladder_endo<FQ_LADDER_ASM ? 3 : LADDER_CH, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);      // the product kernel's ladder: the asm bodies since round 4
     uint64_t t4 = stamp();
     u64 o[20];
     store_r1(o, Q);
@@ -63,14 +62,13 @@ int main() {
     for (size_t i = 0; i < hp.size(); i++) hp[i] = (i & 1) ? (rnd() >> 1) : rnd();          // any residues: timing does not care whether they are points
     CHECK(hipMemcpy(s, hs.data(), n * 32, hipMemcpyHostToDevice)); CHECK(hipMemcpy(p, hp.data(), n * 160, hipMemcpyHostToDevice));
     const char* names[4] = { "as shipped", "ladder gathers always entry 0", "no table construction", "table to packed slots (FULL)" };
-    for (int variant = 0; variant < 4; variant++) {
+    for (int variant = 0; variant < 3; variant++) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); float ms = 0, best = 1e9;
         for (int rep = 0; rep < 60; rep++) {
             CHECK(hipEventRecord(e0));
             if (variant == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
             else if (variant == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
-            else if (variant == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
-            else hipLaunchKernelGGL(k<3>, dim3(512), dim3(256), 0, 0, s, p, o, scr, st);
+            else hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
             CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 40 && ms < best) best = ms;
         }
