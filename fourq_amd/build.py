@@ -39,11 +39,12 @@ RESOURCE_POLICY = [
     (r"ladder_kernel<\d, 2, false", "occupancy", lambda v: v >= 2, "the two-kernel route's MUL ladders run the asm bodies at 2 waves per SIMD"),
     (r"ladder_kernel<\d, 1, \w+, \w+, false>", "scratch", lambda v: v == 0, "the fixed-base ladders (MUL and DH) must not spill"),
     (r"ladder_kernel<\d, 1, \w+, \w+, false>", "occupancy", lambda v: v >= 2, "the fixed-base ladders run the asm bodies at 2 waves per SIMD"),
-    (r"ladder_kernel<\d, 1, \w+, \w+, true>", "scratch", lambda v: v == 0, "the constant-time fixed-base ladders must not spill (their DH flavours are built for 3 waves per SIMD for that)"),
+    (r"ladder_kernel<\d, 1, \w+, \w+, true>", "scratch", lambda v: v == 0, "the constant-time fixed-base ladders must not spill"),
     (r"ladder_kernel<\d, 0,", "scratch", lambda v: v == 0, "the fused variable-base kernels must not spill to memory (AGPR copies are fine)"),
     (r"pair_kernel<", "scratch", lambda v: v == 0, "the two-lanes-per-element kernel must not spill"),
     (r"prep_kernel<0, \w+>\(", "occupancy", lambda v: v >= 2, "prep_kernel<ENDO> hides its read-backs behind a second wave per SIMD"),
-    (r"mixed_ct_tail_kernel<", "occupancy", lambda v: v >= 4, "the constant-time mixed-batch tail runs beside nothing only if it fits four waves per SIMD"),
+    (r"mixed_ct_tail_kernel<", "occupancy", lambda v: v >= 2, "the constant-time mixed-batch tail runs the asm bodies at two waves per SIMD"),
+    (r"mixed_ct_tail_kernel<", "scratch", lambda v: v == 0, "the constant-time mixed-batch tail must not spill"),
     (r"comb_kernel<true, false>", "scratch", lambda v: v == 0, "the keygen comb of large batches (deferred normalisation) must not touch scratch memory"),
     (r"comb_kernel<false, false>", "scratch", lambda v: v <= 16, "the keygen comb with its inversion in the kernel parks 4 registers around the call: no more than that"),
 ]

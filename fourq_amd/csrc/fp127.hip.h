@@ -36,6 +36,11 @@ typedef int64_t i64;
 #ifndef FQ_CHAIN
 #define FQ_CHAIN 0
 #endif
+// FQ_MUL_ASM=1: in a translation unit with FQ_CHAIN=0 the GF(p^2) products and squares of the unsigned flavour are the generated
+// instruction streams FQ_ASM_MULU / FQ_ASM_SQRU (ladder_asm.hip.h, tools/asmgen/gen_ladder_step.py): no fences, no hazard nops.
+#ifndef FQ_MUL_ASM
+#define FQ_MUL_ASM 1
+#endif
 
 constexpr u32 LIMB_BITS = 26;
 constexpr u32 LIMB_MASK = (1u << LIMB_BITS) - 1;
@@ -247,12 +252,16 @@ template <int A, int B> FQ_DEV Fe2<1> fe2_mul_plain(const Fe2<A>& a, const Fe2<B
 // signed flavour at the end of this file); the plain name follows the translation unit's default
 template <int A, int B> FQ_DEV Fe2<1> fe2_mul_signed(const Fe2<A>& a, const Fe2<B>& b);
 template <int A> FQ_DEV Fe2<1> fe2_sqr_signed(const Fe2<A>& a);
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul_asm(const Fe2<A>& a, const Fe2<B>& b);      // ladder_asm.hip.h
+template <int A> FQ_DEV Fe2<1> fe2_sqr_asm(const Fe2<A>& a);
 template <int MODE, int A, int B> FQ_DEV Fe2<1> fe2_mulx(const Fe2<A>& a, const Fe2<B>& b) {
-    if constexpr (MODE == 2) return fe2_mul_signed(a, b);
+    if constexpr (MODE == 3) return fe2_mul_asm(a, b);
+    else if constexpr (MODE == 2) return fe2_mul_signed(a, b);
     else if constexpr (MODE == 1) return fe2_mul_chain(a, b);
     else return fe2_mul_plain(a, b);
 }
-template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) { return fe2_mulx<(FQ_CHAIN != 0) ? 1 : 0>(a, b); }
+constexpr int FE2_DEFAULT_MODE = (FQ_CHAIN != 0) ? 1 : ((FQ_MUL_ASM != 0) ? 3 : 0);
+template <int A, int B> FQ_DEV Fe2<1> fe2_mul(const Fe2<A>& a, const Fe2<B>& b) { return fe2_mulx<FE2_DEFAULT_MODE>(a, b); }
 // (a0 + a1 i)^2 = (a0 + a1)(a0 - a1) + (2 a0 a1) i                               fields.py:176-181
 template <int A> FQ_DEV Fe2<1> fe2_sqr_chain(const Fe2<A>& a) {
     Fe<2 * A> s = fe_add(a.re, a.im);
@@ -296,11 +305,12 @@ template <int A> FQ_DEV Fe2<1> fe2_sqr_plain(const Fe2<A>& a) {
 }
 
 template <int MODE, int A> FQ_DEV Fe2<1> fe2_sqrx(const Fe2<A>& a) {
-    if constexpr (MODE == 2) return fe2_sqr_signed(a);
+    if constexpr (MODE == 3) return fe2_sqr_asm(a);
+    else if constexpr (MODE == 2) return fe2_sqr_signed(a);
     else if constexpr (MODE == 1) return fe2_sqr_chain(a);
     else return fe2_sqr_plain(a);
 }
-template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) { return fe2_sqrx<(FQ_CHAIN != 0) ? 1 : 0>(a); }
+template <int A> FQ_DEV Fe2<1> fe2_sqr(const Fe2<A>& a) { return fe2_sqrx<FE2_DEFAULT_MODE>(a); }
 
 // ---- canonical form, packing --------------------------------------------------------------------
 // 128-bit little-endian container (what the C ABI carries) <-> limbs.

@@ -284,6 +284,13 @@ constexpr int LADDER_CH = 2;
 #ifndef FQ_PREBUILT_ASM
 #define FQ_PREBUILT_ASM 1
 #endif
+// the constant-time ladders on the asm bodies: the whole-table scan (select trees, compiler code) produces the entry, the bodies consume it
+#ifndef FQ_CT_LDS_ASM
+#define FQ_CT_LDS_ASM 1
+#endif
+#ifndef FQ_CT_FUSED_ASM
+#define FQ_CT_FUSED_ASM 1
+#endif
 // TOUCH: the two-kernel route's ladder reads a lane's table entry (one 128-byte line of its scratch slot) inside the
 // addition, with no registers to spare for issuing the eight loads a doubling ahead (128-VGPR budget).  A one-dword load of the
 // line at the top of the step, result unused, starts the HBM / Infinity-Cache fetch early: the real loads then hit L2.
@@ -377,13 +384,26 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
 
 // The ladders with constant-time selection (curve.hip.h, "constant-time selection"): `src` reads the whole table at
 // every step.  Same digits, same DAG, same R1 tuple as the ladders above.
+// the four coordinates of entry `digit` out of a scanned table, as they are stored (add_asm applies the sign: masked selects, no address)
+template <typename SRC> FQ_DEV EntryRegs scan_entry(const SRC& src, u32 digit_value) {
+    const typename SRC::Bits digit(digit_value);
+    EntryRegs t;
+    t.N = src.coord(digit, 0); t.D = src.coord(digit, 1); t.E = src.coord(digit, 2); t.F = src.coord(digit, 3);
+    return t;
+}
 template <int CH, typename SRC> FQ_DEV R1 ladder_endo_scan(const EndoDigits& e, const SRC& src) {
     Proj<1, 1, 1> q4 = start_scan(src, e.top & 7, 0u);
     R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
-        Q = dbl<CH>(Q.X, Q.Y, Q.Z);
-        Q = add_scan<CH>(Q, src, endo_digit(e, i), endo_neg_mask(e, i));
+        if constexpr (CH == 3) {                  // the asm bodies: the scan's select trees hand them the entry as operands
+            Fe2<1> T;
+            dblt_asm(Q.X, Q.Y, Q.Z, T);
+            add_asm(Q, T, scan_entry(src, endo_digit(e, i)), endo_neg_mask(e, i));
+        } else {
+            Q = dbl<CH>(Q.X, Q.Y, Q.Z);
+            Q = add_scan<CH>(Q, src, endo_digit(e, i), endo_neg_mask(e, i));
+        }
     }
     return ladder_result<CH>(Q);
 }
@@ -394,9 +414,17 @@ template <int CH, typename SRC> FQ_DEV R1 ladder_windowed_scan(const WinScalar& 
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
         code = win_code_from_window(win_window(w, i));
+        if constexpr (CH == 3) {
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
-        Q = add_scan<CH>(Q, src, code & 7, (code >> 3) - 1u);
+            for (int k = 0; k < 3; k++) dbl_asm(Q.X, Q.Y, Q.Z);
+            Fe2<1> T;
+            dblt_asm(Q.X, Q.Y, Q.Z, T);
+            add_asm(Q, T, scan_entry(src, code & 7), (code >> 3) - 1u);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) Q = dbl<CH>(Q.X, Q.Y, Q.Z);
+            Q = add_scan<CH>(Q, src, code & 7, (code >> 3) - 1u);
+        }
     }
     return ladder_result<CH>(Q);
 }
@@ -495,6 +523,7 @@ __global__ __launch_bounds__(BLOCK) void prep_kernel(LadderArgs a) {
 constexpr int ladder_waves(int src, bool dh, bool ct) {       // wave slots per SIMD a ladder kernel is built for
     if (src == FUSED) return 1;                                // the endomorphisms' 256 VGPRs and the CU's whole LDS
     if (!ct && FQ_LADDER_ASM && ((src == LDS && FQ_LDS_ASM) || (src == PREBUILT && FQ_PREBUILT_ASM && !dh))) return 2;   // the asm bodies: 256 VGPRs
+    if (ct && src == LDS && FQ_LADDER_ASM && FQ_CT_LDS_ASM) return 2;
     if (ct && src == LDS && dh) return 3;                      // the scan's select tree + DH's epilogue spill at 128 VGPRs (52-80 bytes per lane)
     return 4;
 }
@@ -548,7 +577,8 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
             }
         }
         R1 Q;
-        constexpr int CH = ((SRC == FUSED || (SRC == LDS && FQ_LDS_ASM) || (SRC == PREBUILT && FQ_PREBUILT_ASM && !DH)) && !CT && FQ_LADDER_ASM) ? 3 : LADDER_CH;
+        constexpr bool CT_ASM = CT && FQ_LADDER_ASM && ((SRC == LDS && FQ_CT_LDS_ASM) || (SRC == FUSED && FQ_CT_FUSED_ASM));
+        constexpr int CH = (((SRC == FUSED || (SRC == LDS && FQ_LDS_ASM) || (SRC == PREBUILT && FQ_PREBUILT_ASM && !DH)) && !CT && FQ_LADDER_ASM) || CT_ASM) ? 3 : LADDER_CH;
         if (ALGO == ENDO) {
             u64 v[4];
             decompose(m, v);
@@ -741,7 +771,7 @@ __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, con
     const u32 var_items = (n_var + 63) / 64, total = var_items + (n_fix + 63) / 64;
     u32* slot = a.scratch + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * NDSlots::SLOT;
     const u32 lane = threadIdx.x & 63;
-    constexpr int CH = (!CT && FQ_LADDER_ASM) ? 3 : LADDER_CH;
+    constexpr int CH = (FQ_LADDER_ASM && (!CT || FQ_CT_FUSED_ASM)) ? 3 : LADDER_CH;
 #pragma unroll 1
     for (;;) {
         u32 item = 0;
@@ -804,14 +834,14 @@ __global__ void split_counts_kernel(u32* counts, u32 lanes, u32 limit) {        
     counts[5] = cut ? rem : 0u;
 }
 template <int UNIT_ONLY = 0>
-__global__ __launch_bounds__(BLOCK, 4) void mixed_ct_tail_kernel(LadderArgs a, const u32* fix_list, const u32* var_list, const u32* counts, const u32* over_scratch) {
+__global__ __launch_bounds__(BLOCK, (FQ_LADDER_ASM && FQ_CT_LDS_ASM) ? 2 : 4) void mixed_ct_tail_kernel(LadderArgs a, const u32* fix_list, const u32* var_list, const u32* counts, const u32* over_scratch) {
     __shared__ __attribute__((aligned(16))) u32 lds_table[8 * LDS_ENTRY_U32];
     for (int i = threadIdx.x; i < 8 * R2_LIMBS; i += BLOCK)
         lds_table[(i / R2_LIMBS) * LDS_ENTRY_U32 + (i % R2_LIMBS)] = a.table[i];
     __syncthreads();
     const u32 n_fix = counts[1], fused = counts[4], total = n_fix + counts[5];
     const u32 lanes = gridDim.x * BLOCK, n_round = (total + BLOCK - 1) / BLOCK * BLOCK;
-    constexpr int CH = LADDER_CH;
+    constexpr int CH = (FQ_LADDER_ASM && FQ_CT_LDS_ASM) ? 3 : LADDER_CH;
 #pragma unroll 1
     for (u32 it = blockIdx.x * BLOCK + threadIdx.x; it < n_round; it += lanes) {
         const bool live = it < total;

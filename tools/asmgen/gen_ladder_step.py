@@ -50,6 +50,7 @@ class Prog:
     def __init__(self):
         self.ins = []                   # (mnemonic, template, defs, uses)
         self.n = 0
+        self.signed = True              # False: the unsigned flavour of fp127.hip.h (v_mad_u64_u32, logical carry shifts)
 
     def v(self, name="t"):
         self.n += 1
@@ -380,7 +381,53 @@ VARIANTS = [("STEP_V3", "H as the assembler lays it out (no placement)", dict(al
             ("STEP_V6", "a column's real chain, then its imaginary chain (dependent neighbours)", dict(seq=True))]
 
 
-BODIES = [("DBL", body_dbl), ("DBLT", body_dblt), ("ADD", body_add), ("STEP", body_step)]
+def operand_vec(name, base, k=5):
+    return [V("%s%d" % (name, i), fixed="%%%d" % (base + i)) for i in range(k)]
+
+
+def body_mulu():
+    """One GF(p^2) product of the UNSIGNED flavour (fe2_mul_plain of fp127.hip.h: non-negative lazy limbs, the caller passes the
+    biased negation of a.im): operands out | a.re a.im (-a.im) | b | mask.  No placement of its own: the build's placement pass
+    (tools/asmgen/place_asm.py) sees these instructions like hipcc's."""
+    b = Body([("fe2", "C"), ("fe2", "A")], align=0)
+    b.g.signed = False
+    na = operand_vec("na", 20)
+    B = fixed_fe2(25)
+    b.mask = V("mask", fixed="%35")
+    b.n_operands = 36
+    b.mul(b.A, na, B, b.times8(B), out=b.C)
+    return b
+
+
+def body_sqru():
+    """One GF(p^2) square of the unsigned flavour as its two GF(p) products re = d * s, im = t * a.im (d = a.re - a.im biased,
+    s = a.re + a.im, t = 2 a.re: computed by the caller): operands out | d | s | t | a.im | mask."""
+    b = Body([("fe2", "C")], align=0)
+    b.g.signed = False
+    d, s, t, im = (operand_vec(n, 10 + 5 * k) for k, n in enumerate(("d", "s", "t", "im")))
+    b.mask = V("mask", fixed="%30")
+    b.n_operands = 31
+    g = b.g
+    s8, i8 = [None] + g.vec("e", 4), [None] + g.vec("e", 4)
+    for j in range(1, 5):
+        g.shl(s8[j], 3, s[j])
+    for j in range(1, 5):
+        g.shl(i8[j], 3, im[j])
+    tr, ti = [], []
+    for K in range(5):
+        r, m = [], []
+        for i in range(5):
+            j = K - i
+            r.append((d[i], s[j]) if j >= 0 else (d[i], s8[j + 5]))
+            m.append((t[i], im[j]) if j >= 0 else (t[i], i8[j + 5]))
+        tr.append(r)
+        ti.append(m)
+    b.columns(tr, ti, b.C)
+    return b
+
+
+SMALL_BODIES, SMALL_POOL_LO = ("MULU", "SQRU"), 236          # single products: 16 temporaries, their own short clobber list
+BODIES = [("DBL", body_dbl), ("DBLT", body_dblt), ("ADD", body_add), ("STEP", body_step), ("MULU", body_mulu), ("SQRU", body_sqru)]
 
 
 def allocate(prog, POOL_LO=POOL_LO):
@@ -455,14 +502,16 @@ def preg(p):
 
 def render(prog):
     lines = []
+    mad_mn = "v_mad_i64_i32" if prog.signed else "v_mad_u64_u32"
+    shr_mn = "v_ashrrev_i64" if prog.signed else "v_lshrrev_b64"
     for mn, fmt, defs, uses in prog.ins:
         tag = [u for u in uses if isinstance(u, tuple)]
         if fmt == "mad":
             _, out, a, b, acc = tag[0]
-            lines.append("v_mad_i64_i32 %s, vcc, %s, %s, %s" % (preg(out), reg(a), reg(b), preg(acc) if acc is not None else "0"))
+            lines.append("%s %s, vcc, %s, %s, %s" % (mad_mn, preg(out), reg(a), reg(b), preg(acc) if acc is not None else "0"))
         elif fmt == "ashr":
             _, d, k, s = tag[0]
-            lines.append("v_ashrrev_i64 %s, %d, %s" % (preg(d), k, preg(s)))
+            lines.append("%s %s, %d, %s" % (shr_mn, preg(d), k, preg(s)))
         elif fmt == "lshladd":
             _, d, s, k, c = tag[0]
             lines.append("v_lshl_add_u64 %s, %s, %d, %s" % (preg(d), preg(s), k, preg(c)))
@@ -508,7 +557,7 @@ def main():
     pool_lo = 128 if args.variants else POOL_LO              # the experiments may use a larger pool
     for name, make in bodies:
         b = make()
-        peak = allocate(b.g, pool_lo)
+        peak = allocate(b.g, SMALL_POOL_LO if name in SMALL_BODIES else pool_lo)
         lines = place(render(b.g), b.align)
         built.append((name, b, peak, lines, collections.Counter(ln.split()[0].replace('_e64', '_e32') for ln in lines if not ln.startswith('.'))))
     if args.stats:
@@ -528,6 +577,11 @@ def main():
     for r in range(pool_lo, POOL_HI + 1):
         out.write(", \"v%d\"" % r)
     out.write("\n")
+    if not args.variants:
+        out.write("#define FQ_ASM_SMALL_CLOBBERS \"vcc\"")
+        for r in range(SMALL_POOL_LO, POOL_HI + 1):
+            out.write(", \"v%d\"" % r)
+        out.write("\n")
     for name, b, peak, lines, census in built:
         out.write("// %s: %d instructions (%s), peak %d temporaries\n" % (name, len(lines), ", ".join("%d %s" % (v, k) for k, v in census.most_common()), peak))
         out.write("#define FQ_ASM_%s \\\n" % name)

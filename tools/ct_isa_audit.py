@@ -82,7 +82,8 @@ def operands(ins):
 ADDRESS_OPS = ("v_add_u32", "v_add_co_u32", "v_addc_co_u32", "v_add_nc_u32", "v_add3_u32", "v_lshl_add_u32", "v_lshl_add_u64", "v_add_lshl_u32",
                "v_mov_b32", "v_mov_b64", "v_or_b32", "v_lshlrev_b32", "v_lshlrev_b64", "v_accvgpr_read", "v_accvgpr_write", "v_mad_u32_u24", "v_mul_u32_u24",
                "v_and_b32", "v_or3_b32", "v_lshl_or_b32", "v_and_or_b32")
-LADDER_MADS = (1300, 1200, 650)      # static multiply-adds of one ladder step (DBL + ADD; 4 DBL in an inner loop + ADD) / one comb column / a pair-lane step
+LADDER_MADS = (1300, 1200, 1800, 650)      # static multiply-adds of one ladder step (DBL + ADD; 4 DBL in an inner loop + ADD; since round 4's asm bodies:
+                                           # 3 DBL in an inner loop + DBL-with-T + ADD = 500 + 600 + 700) / one comb column / a pair-lane step
 # four lanes per element (pair_kernel<..., 4>): a ladder step is known by its multiply-adds AND its exchanges between the element's two pairs
 # (v_mov_b32_dpp quad_perm:[2,3,0,1], five per shared result): MUL_endo 350 / 35 (7 results), MUL_windowed 500 / 50 (the loop of three doublings
 # counted once: 3 + 4 + 3 results).  The table-building loops of the same kernels share 3 results per addition (300 / 15).

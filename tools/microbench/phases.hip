@@ -18,7 +18,24 @@ using namespace fq;
 
 FQ_DEV uint64_t stamp() { uint64_t t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
 
-template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* scalars, const u64* points, u64* out, u32* scratch, uint64_t* stamps) {
+// the product's MUL_endo ladder (ladder_endo<3, true, NDSlots, LdsEF> of kernels.hip.h) with the entry index of the HBM-side gather (N, D)
+// and of the LDS read (E, F) masked by run-time values: 7 = by digit as shipped, 0 = always entry 0 (same instructions, one address)
+FQ_DEV R1 ladder_probe(const EndoDigits& e, const u32* tbl, const LdsEF& ef, u32 gmask, u32 lmask) {
+    Proj<1, 1, 1> q4 = start_table<NDSlots>(tbl + (e.top & 7) * NDSlots::ENTRY, 0u);
+    q4.Z = ef.get(e.top & 7, 0);
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+#pragma unroll 1
+    for (int i = 63; i >= 0; i--) {
+        const u32 digit = endo_digit(e, i);
+        const u32 neg = endo_neg_mask(e, i);
+        EntryRegs t = load_entry<NDSlots>(tbl + (digit & gmask) * NDSlots::ENTRY, neg, digit & lmask, ef);
+        Fe2<1> T;
+        dblt_asm(Q.X, Q.Y, Q.Z, T);
+        add_asm(Q, T, t, neg);
+    }
+    return ladder_result<3>(Q);
+}
+template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* scalars, const u64* points, u64* out, u32* scratch, uint64_t* stamps, u32 gmask, u32 lmask) {
     __shared__ __attribute__((aligned(16))) u32 lds_mem[EF_LDS_U32];
     LdsEF ef; ef.lane = reinterpret_cast<uint2*>(lds_mem) + threadIdx.x;
     const u32 id = blockIdx.x * 256 + threadIdx.x;
@@ -37,7 +54,8 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     EndoDigits e = recode(v);
     if (VARIANT == 1) { e.d[0] = e.d[1] = e.d[2] = 0; e.top = 0; }
     uint64_t t3 = stamp();
-    R1 Q = ladder_endo<FQ_LADDER_ASM ? 3 : LADDER_CH, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);      // the product kernel's ladder: the asm bodies since round 4
+    R1 Q = (VARIANT >= 3) ? ladder_probe(e, (const u32*)slot, ef, gmask, lmask)
+                          : ladder_endo<FQ_LADDER_ASM ? 3 : LADDER_CH, true, NDSlots>(e, (const u32*)slot, NDSlots::ENTRY, ef);      // the product kernel's ladder: the asm bodies since round 4
     uint64_t t4 = stamp();
     u64 o[20];
     store_r1(o, Q);
@@ -61,14 +79,16 @@ int main() {
     for (auto& v : hs) v = rnd();
     for (size_t i = 0; i < hp.size(); i++) hp[i] = (i & 1) ? (rnd() >> 1) : rnd();          // any residues: timing does not care whether they are points
     CHECK(hipMemcpy(s, hs.data(), n * 32, hipMemcpyHostToDevice)); CHECK(hipMemcpy(p, hp.data(), n * 160, hipMemcpyHostToDevice));
-    const char* names[4] = { "as shipped", "ladder gathers always entry 0", "no table construction", "table to packed slots (FULL)" };
-    for (int variant = 0; variant < 3; variant++) {
+    const char* names[6] = { "as shipped", "ladder gathers always entry 0", "no table construction", "probe ladder, by digit (= shipped)",
+                             "probe: N, D (HBM side) always entry 0", "probe: E, F (LDS) always entry 0" };
+    for (int variant = 0; variant < 6; variant++) {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1)); float ms = 0, best = 1e9;
         for (int rep = 0; rep < 60; rep++) {
             CHECK(hipEventRecord(e0));
-            if (variant == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
-            else if (variant == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
-            else hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st);
+            if (variant == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st, 7u, 7u);
+            else if (variant == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st, 7u, 7u);
+            else if (variant == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st, 7u, 7u);
+            else hipLaunchKernelGGL(k<3>, dim3(256), dim3(256), 0, 0, s, p, o, scr, st, variant == 4 ? 0u : 7u, variant == 5 ? 0u : 7u);
             CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize()); CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (rep > 40 && ms < best) best = ms;
         }
