@@ -43,23 +43,23 @@ VALU_MAD_PEAK_MEASURED = 1024 * 64 / 1.84e-9
 # 6 DBL + 27 mixed ADD (7M) = 21 900 + its share of an inversion): DESIGN.md section 5.
 WORKLOADS = {
     "cfg2": dict(batch=1 << 16, steps=500, bytes=32 + 160 + 160, alg_mads=49_440, mads=97_600, seed=20002,
-                 kernel="ladder_kernel<ENDO, FUSED>", unit="MUL_endo(m, P), variable base",
+                 kernel="ladder_kernel<ENDO, FUSED> (table_endo + recoding + 64 hand-scheduled ladder steps, one wave per SIMD)", unit="MUL_endo(m, P), variable base",
                  text="BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
                       "projective N-torsion points, raw R1 in/out resident in HBM"),
     "cfg3": dict(batch=1 << 20, steps=60, bytes=32 + 160, alg_mads=91_264, mads=173_600, seed=30002,
-                 kernel="ladder_kernel<WINDOWED, LDS>", unit="MUL_windowed(m, G, table)",
+                 kernel="ladder_kernel<WINDOWED, LDS> (asm ladder bodies, two waves per SIMD)", unit="MUL_windowed(m, G, table)",
                  text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
     # cfg4: alg_mads prices BOTH halves at the reference's algorithm (DH_endo with table_endo([392]G): 47 616; DH_endo variable
     # base: 55 072).  The keygen half actually runs the comb (6 DBL + 27 mixed ADD of 7 M: 6 x 272 + 27 x 336 = 10 704 units
     # + its share of an inversion ~ 400), so alg_mads_run = 11 104 + 55 072 is the figure comparable with the executed one.
     "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, alg_mads_run=11_104 + 55_072, mads=22_500 + 97_600 + 6_800, seed=40002,
-                 kernel="comb_kernel + prep_kernel/ladder_kernel<ENDO, PREBUILT, DH> + normalize_kernel<8>",
+                 kernel="comb_kernel + ladder_kernel<ENDO, FUSED, DH, DEFER> (one launch for the eight generations, asm ladder bodies) + normalize_kernel<8>",
                  unit="exchange = DH_endo(a, DH_endo(b, G)): two DH_core evaluations",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
                       "(first half fixed-base through the 1024-point comb of [392]G, same affine outputs as with table_endo([392]G); "
                       "second half variable-base); affine in/out"),
     "cfg5": dict(batch=1 << 17, steps=300, bytes=(192 + 352) // 2, alg_mads=(41_984 + 49_440) // 2, mads=(83_300 + 97_600) // 2, seed=50002,
-                 kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer",
+                 kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer (asm ladder bodies, two waves per SIMD)",
                  unit="MUL_endo, 50% fixed base / 50% variable base",
                  text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo; "
                       "device-side compaction of the variable-base ids, their tables built by prep_kernel, then ONE pointer-selected "
@@ -417,6 +417,17 @@ class Bench:
                          "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
             "valu_roofline": valu_roofline(wl, n, kernel_ms),
         }
+        # The bound that actually holds (round 4, profiles/r04_ladder_step.txt): with every 8-byte instruction 8-byte aligned a SIMD issues
+        # ONE wave64 VALU instruction per ~4 cycles for this instruction mix, multiply-add or not, at one, two or four waves per SIMD.
+        wave_instr = None if self.eng.ct_select else _pmc_valu_instructions(workload, self.eng.build_id)
+        issue_peak = 1024 * 2.4e9 / 4.0                      # wave64 VALU instructions per second, chip-wide, nominal clock
+        rec["valu_roofline"]["issue"] = {
+            "bound": "valu-issue: one wave64 VALU instruction per SIMD per 4 cycles", "peak": round(issue_peak / 1e9, 1), "unit": "G wave-instructions/s",
+            "wave_instructions_per_step": wave_instr, "instructions_per_unit": None if wave_instr is None else round(wave_instr * 64 / n, 1),
+            "achieved": None if wave_instr is None else round(wave_instr / (kernel_ms * 1e-3) / 1e9, 1),
+            "frac": None if wave_instr is None else round(wave_instr / (kernel_ms * 1e-3) / issue_peak, 4),
+            "source": "SQ_INSTS_VALU of the step's kernels, profiles/pmc_traffic.json (same build-id rule as roofline.traffic)",
+            "note": "what is left on this path is the instruction count per unit, not the schedule, the occupancy or the memory system"}
         return rec, d
 
     def parity_gate(self, workload, d):
@@ -750,6 +761,20 @@ def _pmc_traffic(workload, build_id):
         src["note"] = "the committed PMC profile was taken on another build of the library: no traffic figure is claimed for this one"
         return None, src
     return (data.get("per_workload") or {}).get(workload), src
+
+
+def _pmc_valu_instructions(workload, build_id):
+    """wave64 VALU instructions per bench step (SQ_INSTS_VALU summed over the step's kernels) from the same committed profile, under the
+    same rule: only for the build that is loaded."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            data = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    profiled = (data.get("library_build_ids") or {}).get(workload, data.get("library_build_id"))
+    if not build_id or profiled != build_id:
+        return None
+    return (data.get("valu_wave_instructions_per_step") or {}).get(workload)
 
 
 # ---- launcher ----------------------------------------------------------------------------------------------------

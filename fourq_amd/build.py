@@ -192,8 +192,19 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
     place = "-DFQ_NO_PLACE=1" not in extra_flags
     flags = HIPCC_FLAGS + list(extra_flags) + ['-DFQ_BUILD_ID="%s"' % source_id(extra_flags)]
     objs = [os.path.join(SRC_DIR, os.path.splitext(src)[0] + suffix + ".o") for src in SOURCES]
+    def one(so):
+        try:
+            return compile_unit(so[0], so[1], flags, verbose, place)
+        except RuntimeError as e:
+            if not place:
+                raise
+            # the placement detour failed (an assembler that rejects a re-encoding, a tool that moved): the plain hipcc build of the
+            # same sources is correct, only a percent slower -- build that, and say so loudly
+            print("fourq_amd.build: code placement of %s failed, building it without the pass:\n%s" % (so[0], str(e)[-1500:]), file=sys.stderr)
+            return compile_unit(so[0], so[1], flags, verbose, False)
+
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:      # the translation units in parallel (~1 min each)
-        outs = list(pool.map(lambda so: compile_unit(so[0], so[1], flags, verbose, place), zip(SOURCES, objs)))
+        outs = list(pool.map(one, zip(SOURCES, objs)))
     resources = {}
     for src, out in zip(SOURCES, outs):
         raw = parse_resource_remarks(out)

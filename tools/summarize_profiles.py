@@ -34,7 +34,7 @@ def short(name):
 
 
 traffic_path = os.path.join(dst, "pmc_traffic.json")
-per_workload, build_ids = {}, {}
+per_workload, build_ids, valu_per_workload = {}, {}, {}
 for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
     w = os.path.basename(wdir)
     # gpurun merges a call's files INTO gpurun_out/: a tag used twice leaves two runs side by side -- take the newest of each kind
@@ -69,7 +69,7 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
             kernels[k]["dispatch"] = info[k]
             for c, v in ctrs.items():
                 kernels[k]["counters"][c] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
-    step_traffic = 0.0
+    step_traffic, step_valu = 0.0, 0.0
     for k, rec in kernels.items():
         c = rec["counters"]
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -81,15 +81,18 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
             step_traffic += (2 * fetch_raw + write) * (rec["launches_per_step"] or 0)
         if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c and c["SQ_WAVES"]["mean"]:
             rec["valu_instructions_per_lane"] = c["SQ_INSTS_VALU"]["mean"] / c["SQ_WAVES"]["mean"]
+        if "SQ_INSTS_VALU" in c:
+            step_valu += c["SQ_INSTS_VALU"]["mean"] * (rec["launches_per_step"] or 0)          # wave64 instructions per bench step
     bench = json.load(open(os.path.join(wdir, "bench.json")))
     out = {"workload": w, "bench_ms_per_step": bench["ms_per_step"], "bench_kernel_ms": bench["roofline"]["kernel_ms"],
            "rocprof_ms_per_step": sum(r["rocprof_avg_ns"] * (r["launches_per_step"] or 0) for r in kernels.values()) / 1e6,
-           "hbm_bytes_per_step": step_traffic, "algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_launch"],
+           "hbm_bytes_per_step": step_traffic, "valu_wave_instructions_per_step": step_valu, "algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_launch"],
            "note": "traffic = memory-side (fabric) requests incl. Infinity Cache hits; FETCH_SIZE doubled per the gfx950 correction; "
                    "PMC passes run separately from the kernel trace (10 steps each)", "kernels": kernels}
     with open(os.path.join(dst, "%s_pmc_%s.json" % (tag, w)), "w") as fh:
         json.dump(out, fh, indent=1)
     per_workload[w] = step_traffic
+    valu_per_workload[w] = step_valu
     build_ids[w] = ((bench.get("config") or {}).get("library") or {}).get("build_id")
     print("%s: bench %.4f ms/step, rocprof sum %.4f ms/step, traffic %.1f MB/step (algorithmic %.1f MB)" % (
         w, out["bench_ms_per_step"], out["rocprof_ms_per_step"], step_traffic / 1e6, out["algorithmic_bytes_per_step"] / 1e6))
@@ -100,10 +103,11 @@ if per_workload:
         with open(traffic_path) as fh:
             old = json.load(fh)
         per_workload = dict(old.get("per_workload") or {}, **per_workload)
+        valu_per_workload = dict(old.get("valu_wave_instructions_per_step") or {}, **valu_per_workload)
         build_ids = dict(old.get("library_build_ids") or {}, **build_ids)
     except (OSError, ValueError):
         pass
-    data = {"hbm_bytes_per_launch": per_workload.get("cfg2"), "per_workload": per_workload, "source": "profiles/%s_pmc_<workload>.json" % tag,
+    data = {"hbm_bytes_per_launch": per_workload.get("cfg2"), "per_workload": per_workload, "valu_wave_instructions_per_step": valu_per_workload, "source": "profiles/%s_pmc_<workload>.json" % tag,
             "library_build_ids": build_ids, "library_build_id": build_ids.get("cfg2"),
             "note": "HBM-side bytes per bench step: sum over the step's kernels of (2 x FETCH_SIZE + WRITE_SIZE) per launch x launches per step"}
     with open(traffic_path, "w") as fh:
