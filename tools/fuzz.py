@@ -76,7 +76,7 @@ while time.time() < t_end:
             if rng.random() < 0.2:
                 s[rng.randrange(n)] = 0
             pts = eng.mul_endo_fixed(scalars(n), te)
-            what = rng.choice(["endo", "win", "endo_fixed", "win_fixed", "mixed", "dh_endo", "dh_win", "dh_fixed", "comb", "pinned", "dh_bytes", "exchange"])
+            what = rng.choice(["endo", "win", "endo_fixed", "win_fixed", "mixed", "dh_endo", "dh_win", "dh_fixed", "comb", "pinned", "dh_bytes", "exchange", "mul_affine", "mul_bytes"])
             if what == "endo":
                 ok = np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
             elif what == "pinned":                           # the same from pinned host arrays (DMA in place, no bounce)
@@ -106,6 +106,23 @@ while time.time() < t_end:
                     want[wst != 0] = 0
                     got, gst = eng.dh_exchange(s, b2, gaff)
                     ok = np.array_equal(got, want) and np.array_equal(gst, wst)
+            elif what in ("mul_affine", "mul_bytes"):        # round 4: MUL_* with affine / encoded I/O, both algorithms
+                kind, okind = rng.choice([("endo", oc.ENDO), ("windowed", oc.WINDOWED)])
+                aff_in = oc.r1_to_affine(pts)
+                lifted = np.zeros((n, 20), dtype=np.uint64)
+                lifted[:, 0:8] = aff_in; lifted[:, 8] = 1; lifted[:, 12:20] = aff_in
+                want = oc.r1_to_affine(oc.mul(okind, s, lifted))
+                if what == "mul_affine":
+                    ok = np.array_equal(eng.mul_affine(s, aff_in, kind=kind), want)
+                else:
+                    keys = oc.encode(aff_in).copy()
+                    wenc, wst = oc.encode(want).copy(), np.zeros(n, dtype=np.uint8)
+                    if n > 3:
+                        j = rng.randrange(n)
+                        keys[j, 15] |= 0x80                  # a reserved bit: decode status 1
+                        wenc[j], wst[j] = 0, 16 + 1
+                    got, gst = eng.mul_bytes(s, keys, kind=kind)
+                    ok = np.array_equal(got, wenc) and np.array_equal(gst, wst)
             elif what == "win":
                 ok = np.array_equal(eng.mul_windowed(s, pts), oc.mul(oc.WINDOWED, s, pts))
             elif what == "endo_fixed":
