@@ -149,6 +149,38 @@ def _run(cmd, verbose=False):
     return proc.stdout
 
 
+def check_register_ranges(asm_path):
+    """The generated bodies (ladder_asm.hip.h) name their temporaries as PHYSICAL registers (v168-v255, v236-v255) and declare them as
+    clobbers.  hipcc counts clobbered registers into a kernel's allocation -- unless the kernel's launch bounds cap its budget below them, in
+    which case it only warns ("reserved registers") and the instruction would address registers the wave does not own.  No such kernel may
+    reach a body: every kernel's highest VGPR named in its code must lie inside its `.amdhsa_next_free_vgpr`."""
+    kernel, highest, alloc = None, {}, {}
+    with open(asm_path) as fh:
+        for ln in fh:
+            m = re.match(r"^(_Z\w+):", ln)
+            if m:
+                kernel = m.group(1)
+                continue
+            m = re.match(r"\s*\.amdhsa_kernel\s+(\S+)", ln)
+            if m:
+                kernel = m.group(1)
+                continue
+            m = re.match(r"\s*\.amdhsa_next_free_vgpr\s+(\d+)", ln)
+            if m and kernel:
+                alloc[kernel] = int(m.group(1))
+                continue
+            t = ln.strip()
+            if kernel is None or not t or t[0] in ";.":
+                continue
+            for a, b in re.findall(r"\bv(\d+)\b|\bv\[\d+:(\d+)\]", t):
+                r = int(a or b)
+                if r > highest.get(kernel, -1):
+                    highest[kernel] = r
+    bad = ["%s names v%d but owns %d VGPRs" % (k, h, alloc[k]) for k, h in highest.items() if k in alloc and h >= alloc[k]]
+    if bad:
+        raise RuntimeError("a kernel reaches an asm body whose registers it does not own:\n  " + "\n  ".join(bad))
+
+
 def compile_unit(src, obj, flags, verbose=False, place=True):
     """One translation unit -> object file; returns hipcc's remarks (the kernel resource report).  With `place`, the device code
     takes the detour through placed assembly text described at PLACE_TOOL."""
@@ -162,6 +194,7 @@ def compile_unit(src, obj, flags, verbose=False, place=True):
     stem = os.path.splitext(obj)[0]
     dev_s, placed_s, dev_o, hsaco, fatbin = stem + ".dev.s", stem + ".placed.s", stem + ".dev.o", stem + ".hsaco", stem + ".hipfb"
     remarks = _run([_hipcc()] + flags + ["--cuda-device-only", "-S", "-o", dev_s, src_path], verbose)
+    check_register_ranges(dev_s)
     stats = place_asm.place_file(dev_s, placed_s)
     if verbose:
         print("%s: %d of %d 8-byte instructions at 4 mod 8 before placement, %d after" % (
