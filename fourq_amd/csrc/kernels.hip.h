@@ -485,6 +485,53 @@ template <typename L, typename EF> FQ_DEV void build_table_endo_lds(const R1& P,
     store_result();                            // T[7]
 }
 
+// The same construction with every formula a generated body (ladder_asm.hip.h: tau / upsilon / chi / tau_dual + R1toR3 / R1toR2 /
+// table addition, 22 500 instructions per table against hipcc's 24 400, no register shuffles between products): same parking
+// schedule in LDS, same stores, same tight non-negative entries.  FQ_TABLE_ASM selects it for the fused kernels.
+#ifndef FQ_TABLE_ASM
+#define FQ_TABLE_ASM 1
+#endif
+template <typename L, typename EF> FQ_DEV void build_table_endo_lds_asm(const R1& P, u32* slot, const EF& ef) {
+    static_assert(EF::ON, "needs the LDS copy of E and F");
+    R2 result = r1_to_r2_asm(P);               // T[0]
+    int result_at = 0;
+    const Fe2<1> n0 = result.N, d0 = result.D;
+    Fe2<1> X = P.X, Y = P.Y, Z = P.Z;          // step 0: P; step 1: tau(P); step 2: phi(P)
+    auto store_result = [&]() {
+        store_entry<L>(slot, result_at, result, ef);
+        if (result_at >= 1 && result_at <= 3) ef.park_nd(8 - result_at, result.N, result.D);
+    };
+#pragma unroll 1
+    for (int step = 0; step < 3; step++) {
+        store_result();
+        if (step != 1) {                       // phi and psi share tau(P), curve4q.py:318-322
+            tau_asm(X, Y, Z);
+            if (step == 0) ef.park_xyz(6, X, Y, Z);
+        }
+        if (step == 0) upsilon_asm(X, Y, Z); else chi_asm(X, Y, Z);
+        Fe2<2> N3, D3;
+        Fe2<1> F3;
+        taudual_asm(X, Y, Z, N3, D3, F3);      // (X, Y, Z) = phi(P) / psi(P) / psi(phi(P)); (N3, D3, Z, F3) its R3 form
+        const Fe2<1> E3 = Z;
+        R2 base;
+        base.N = n0; base.D = d0; base.E = ef.get(0, 0); base.F = ef.get(0, 1);
+        const int half = 1 << step;
+#pragma unroll 1
+        for (int m = 0; m < half; m++) {
+            R2 next = base;
+            if (m + 1 < half) { ef.unpark_nd(8 - (m + 1), next.N, next.D); next.E = ef.get((u32)(m + 1), 0); next.F = ef.get((u32)(m + 1), 1); }
+            if (m > 0) store_result();
+            if (m == 0 && step == 0) ef.park_xyz(4, X, Y, Z);
+            if (m == half - 1 && step < 2) ef.unpark_xyz(step == 0 ? 6 : 4, X, Y, Z);   // for the next step
+            result = base;
+            table_add_asm(result, N3, D3, E3, F3);
+            result_at = half + m;
+            base = next;
+        }
+    }
+    store_result();                            // T[7]
+}
+
 FQ_DEV void load_scalar(const u64* p, u64 m[4]) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
@@ -573,7 +620,9 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
                 P = load_r1(a.points + 20 * (size_t)id);
             }
             if constexpr (SRC == FUSED) {
-                if (ALGO == ENDO) build_table_endo_lds<L>(P, slot, ef); else build_table_windowed<L>(P, slot, ef);
+                if constexpr (ALGO == ENDO && FQ_TABLE_ASM && FQ_LADDER_ASM) build_table_endo_lds_asm<L>(P, slot, ef);
+                else if (ALGO == ENDO) build_table_endo_lds<L>(P, slot, ef);
+                else build_table_windowed<L>(P, slot, ef);
             }
         }
         R1 Q;
@@ -788,7 +837,8 @@ __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, con
         R1 Q;
         if (variable) {
             const R1 P = load_r1(a.points + 20 * (size_t)id);
-            build_table_endo_lds<NDSlots>(P, slot, ef);
+            if constexpr (FQ_TABLE_ASM && FQ_LADDER_ASM) build_table_endo_lds_asm<NDSlots>(P, slot, ef);
+            else build_table_endo_lds<NDSlots>(P, slot, ef);
             u64 v[4];
             decompose(m, v);
             const EndoDigits e = recode(v);

@@ -19,6 +19,11 @@ Bodies and their operand order (every Fe2 is ten operands: re limbs 0-4, im limb
   FQ_ASM_DBLT   X, Y, Z in/out | T out | limb mask                          the same plus T = Ta*Tb of the double (R1toR3)
   FQ_ASM_ADD    X, Y, Z in/out | Ta out | Tb out | T in | N, D, E, F in | neg mask | limb mask       ADD_core with +-entry
   FQ_ASM_STEP   X, Y, Z in/out | Ta out | Tb out | N, D, E, F in | neg mask | limb mask              DBLT + ADD in one body
+  FQ_ASM_MULU / SQRU   one product / square of the unsigned flavour (see body_mulu / body_sqru)
+  FQ_ASM_TAU / UPSILON / CHI    X, Y, Z in/out | limb mask                  the endomorphisms' pieces, in place (curve4q.py:258-316)
+  FQ_ASM_TAUDUAL  X, Y, Z in/out | N3, D3, F3 out | limb mask                tau_dual and R1toR3 of the result (E3 is Z)
+  FQ_ASM_R1TOR2   N, D, E, F out | X, Y, Z, Ta, Tb in | limb mask             a tight, non-negative table entry
+  FQ_ASM_TABLEADD N, D, E, F of the entry in/out | N3, D3, E3, F3 in | limb mask     entry <- R1toR2(ADD_core(p, entry))
 """
 import argparse
 import collections
@@ -103,6 +108,18 @@ class Prog:
 
     def mov0(self, d):
         self.emit("v_mov_b32_e32", "v_mov_b32_e32 {0}, 0", [d], [])
+
+    def movk(self, d, value):           # a 32-bit literal (8 bytes)
+        self.emit("v_mov_b32_e32", "v_mov_b32_e32 {0}, 0x%x" % value, [d], [])
+
+    def addk(self, d, value, a):        # d = literal + a
+        self.emit("v_add_u32_e32", "v_add_u32_e32 {0}, 0x%x, {1}" % value, [d], [a])
+
+    def shr(self, d, k, a):             # logical
+        self.op2("v_lshrrev_b32_e32", d, k, a)
+
+    def shl_add(self, d, a, k, c):      # d = (a << k) + c
+        self.emit("v_lshl_add_u32", "v_lshl_add_u32 {0}, {1}, %d, {2}" % k, [d], [a, c])
 
 
 class Fe2:
@@ -346,6 +363,190 @@ class Body:
         self.mul(G2, nG2, F2, F28, out=self.Z)
 
 
+    # ---- table construction (table_endo, curve4q.py:385-403): the endomorphisms and the additions as whole-formula bodies ----
+    UNIT = (1 << 26) + (1 << 15)
+
+    def kmul(self, a, c, name="k", out=None):
+        """a * constant c = (c0, c1) (ints mod p): the constant is the second operand, its limbs and their eightfold come as
+        literals (one v_mov each) and every multiply-add with a ZERO limb of the constant is left out -- most of the curve's
+        constants have three zero limbs in one component."""
+        g = self.g
+        out = out or self.fe2_new(name)
+        lim = [[(c[k] >> (26 * i)) & ((1 << 26) - 1) for i in range(5)] for k in (0, 1)]
+        regs = {}
+
+        def lit(value):
+            if value == 0:
+                return None
+            if value not in regs:
+                regs[value] = g.v("c")
+                g.movk(regs[value], value)
+            return regs[value]
+        na = self.neg_im(a)
+        tr, ti = [], []
+        for K in range(5):
+            r, m = [], []
+            for i in range(5):
+                j = K - i
+                w = 1 if j >= 0 else 8
+                q0, q1 = lit(lim[0][j % 5] * w), lit(lim[1][j % 5] * w)
+                if q0 is not None:
+                    r.append((a.re[i], q0))
+                    m.append((a.im[i], q0))
+                if q1 is not None:
+                    r.append((na[i], q1))
+                    m.append((a.re[i], q1))
+            tr.append(r)
+            ti.append(m)
+        self.columns(tr, ti, out)
+        return out
+
+    def fe2_neg(self, a, name="ng"):
+        r = self.fe2_new(name)
+        for part in ("re", "im"):
+            for i in range(5):
+                self.g.sub(getattr(r, part)[i], 0, getattr(a, part)[i])
+        return r
+
+    def fe2_conj(self, a, name="cj"):       # negates the imaginary part only; the real limbs are shared
+        return Fe2(a.re, self.neg_im(a))
+
+    def tighten(self, a, bound, out=None, name="tg"):
+        """Signed limbs of magnitude <= bound * UNIT -> the same residue as NON-NEGATIVE tight limbs (what a table entry is for every
+        consumer, fe_unsign of fp127.hip.h): add (bound + 1) * (2^130 - 8) in limb form, one 32-bit carry pass."""
+        g = self.g
+        out = out or self.fe2_new(name)
+        M26 = (1 << 26) - 1
+        for src, dst in ((a.re, out.re), (a.im, out.im)):
+            u = g.vec("u")
+            for i in range(5):
+                g.addk(u[i], (bound + 1) * (M26 - 7 if i == 0 else M26), src[i])
+            t = [None] + g.vec("t", 4)
+            c = g.v("c")
+            g.shr(c, 26, u[0]); g.add(t[1], u[1], c)
+            for i in (2, 3, 4):
+                c = g.v("c")
+                g.shr(c, 26, t[i - 1]); g.add(t[i], u[i], c)
+            l0, c = g.v("l"), g.v("c")
+            g.band(l0, self.mask, u[0])
+            g.shr(c, 26, t[4])
+            t0 = g.v("t")
+            g.shl_add(t0, c, 3, l0)                      # < 2^26 + 2^9
+            g.band(dst[0], self.mask, t0)
+            c2, l1 = g.v("c"), g.v("l")
+            g.shr(c2, 26, t0)
+            g.band(l1, self.mask, t[1])
+            g.add(dst[1], l1, c2)
+            for i in (2, 3, 4):
+                g.band(dst[i], self.mask, t[i])
+        return out
+
+    def mulp(self, a, b, name="m", out=None):
+        """a * b with the preparation done here (no sharing): b must be the operand whose eightfold fits (bound <= 3)."""
+        return self.mul(a, self.neg_im(a), b, self.times8(b), name, out=out)
+
+    def f_tau(self, X, Y, Z, oX, oY, oZ, ctau):                            # curve4q.py:258-267
+        A, B = self.side_by_side(lambda: self.sqr(X, name="A"), lambda: self.sqr(Y, name="B"))
+        C = self.fe2_add(A, B, "C")                       # 2
+        D = self.fe2_sub(A, B, "D")                       # 2
+        Zs = self.sqr(Z, name="Zs")
+        t = self.fe2_add(self.fe2_add(Zs, Zs, "z2"), D, "t")          # 4
+        nD = self.neg_im(D)
+        C8 = self.times8(C)
+        x1 = self.kmul(X, ctau, "x1")
+        x2 = self.mulp(Y, x1, "x2")
+        self.mul(D, nD, x2, self.times8(x2), out=oX)
+        y = self.mul(t, self.neg_im(t), C, C8, "y")
+        for part in ("re", "im"):
+            for i in range(5):
+                self.g.sub(getattr(oY, part)[i], 0, getattr(y, part)[i])
+        self.mul(D, nD, C, C8, out=oZ)
+
+    def f_tau_dual(self, X, Y, Z, oX, oY, oZ, oN3, oD3, oF3, ctaudual):     # curve4q.py:269-280 + R1toR3 (:119-126)
+        A, B = self.side_by_side(lambda: self.sqr(X, name="A"), lambda: self.sqr(Y, name="B"))
+        C = self.fe2_add(A, B, "C")                       # 2
+        Ta = self.fe2_sub(B, A, "Ta")                     # 2
+        Zs = self.sqr(Z, name="Zs")
+        D = self.fe2_sub(self.fe2_add(Zs, Zs, "z2"), Ta, "D")         # 4
+        tb1 = self.kmul(X, ctaudual, "tb1")
+        Tb = self.mulp(Y, tb1, "Tb")
+        nD = self.neg_im(D)
+        Tb8 = self.times8(Tb)
+        self.mul(C, self.neg_im(C), Tb, Tb8, out=oX)
+        self.mul(D, nD, Ta, self.times8(Ta), out=oY)
+        self.mul(D, nD, C, self.times8(C), out=oZ)
+        self.mul(Ta, self.neg_im(Ta), Tb, Tb8, out=oF3)   # R1toR3: Ta * Tb
+        self.fe2_add(oX, oY, out=oN3)
+        self.fe2_sub(oY, oX, out=oD3)
+
+    def f_upsilon(self, X, Y, Z, oX, oY, oZ, cphi):                          # curve4q.py:282-302
+        a1 = self.kmul(X, cphi[0], "a1")
+        A = self.mulp(Y, a1, "A")
+        B = self.mulp(Y, Z, "B")
+        C, D = self.side_by_side(lambda: self.sqr(Y, name="C"), lambda: self.sqr(Z, name="D"))
+        F, G = self.side_by_side(lambda: self.sqr(D, name="F"), lambda: self.sqr(B, name="G"))
+        H = self.sqr(C, name="H")
+        I = self.kmul(B, cphi[1], "I")
+        J = self.fe2_add(C, self.kmul(D, cphi[2], "j"), "J")                                        # 2
+        K = self.fe2_add(self.fe2_add(self.kmul(G, cphi[8], "k8"), H, "k"), self.kmul(F, cphi[9], "k9"), "K")    # 3
+        imj, ipj = self.fe2_sub(I, J, "imj"), self.fe2_add(I, J, "ipj")                              # 3, 3
+        x2 = self.mulp(imj, ipj, "x2")
+        L = self.fe2_add(C, self.kmul(D, cphi[4], "l"), "L")                                        # 2
+        Mm = self.kmul(B, cphi[3], "M")
+        lmm, lpm = self.fe2_sub(L, Mm, "lmm"), self.fe2_add(L, Mm, "lpm")                            # 3, 3
+        Nn = self.mulp(lmm, lpm, "Nn")
+        y2 = self.fe2_add(self.fe2_add(H, self.kmul(G, cphi[6], "y6"), "y"), self.kmul(F, cphi[7], "y7"), "y2")  # 3
+        nK = self.neg_im(K)
+        ka = self.mul(K, nK, A, self.times8(A), "ka")
+        self.mulp(ka, x2, out=oX)
+        d5 = self.kmul(D, cphi[5], "d5")
+        dn = self.mulp(d5, Nn, "dn")
+        self.mulp(y2, dn, out=oY)
+        kb = self.mul(K, nK, B, self.times8(B), "kb")
+        self.mulp(kb, Nn, out=oZ)
+        for o in (oX, oY, oZ):                            # conj: the imaginary part negated in place
+            for i in range(5):
+                self.g.sub(o.im[i], 0, o.im[i])
+
+    def f_chi(self, X, Y, Z, oX, oY, oZ, cpsi):                                # curve4q.py:304-316
+        A, B, Zc = self.fe2_conj(X), self.fe2_conj(Y), self.fe2_conj(Z)
+        C, D = self.side_by_side(lambda: self.sqr(Zc, name="C"), lambda: self.sqr(A, name="D"))
+        g1 = self.fe2_add(D, self.kmul(C, cpsi[2], "c2"), "g1")       # 2
+        G = self.mulp(B, g1, "G")
+        h1 = self.fe2_add(D, self.kmul(C, cpsi[4], "c4"), "h1")       # 2
+        H = self.fe2_neg(h1, "H")
+        nH = self.neg_im(H)
+        ac = self.mulp(self.kmul(A, cpsi[1], "a1"), C, "ac")
+        self.mul(H, nH, ac, self.times8(ac), out=oX)
+        y1 = self.fe2_add(D, self.kmul(C, cpsi[3], "c3"), "y1")       # 2
+        G8 = self.times8(G)
+        self.mul(y1, self.neg_im(y1), G, G8, out=oY)
+        self.mul(H, nH, G, G8, out=oZ)
+
+    def f_r1_to_r2(self, X, Y, Z, Ta, Tb, oN, oD, oE, oF, two_d, in_bound=1):    # curve4q.py:109-116; tight non-negative entry
+        self.tighten(self.fe2_add(X, Y, "n"), 2 * in_bound, out=oN)
+        self.tighten(self.fe2_sub(Y, X, "d"), 2 * in_bound, out=oD)
+        self.tighten(self.fe2_add(Z, Z, "e"), 2 * in_bound, out=oE)
+        tt = self.mulp(Ta, Tb, "tt")
+        self.tighten(self.kmul(tt, two_d, "f"), 1, out=oF)
+
+    def f_table_add(self, pN, pD, pE, pF, qN, qD, qE, qF, oN, oD, oE, oF, two_d):   # r1_to_r2(add_core(p, q)), curve4q.py:155-171, :109-116
+        A, B = self.side_by_side(lambda: self.mulp(pD, qD, "A"), lambda: self.mulp(pN, qN, "B"))
+        C, D = self.side_by_side(lambda: self.mulp(qF, pF, "C"), lambda: self.mulp(qE, pE, "D"))
+        E = self.fe2_sub(B, A, "E")
+        F = self.fe2_sub(D, C, "F")
+        G = self.fe2_add(D, C, "G")
+        H = self.fe2_add(B, A, "H")
+        nE, nG = self.neg_im(E), self.neg_im(G)
+        F8, H8 = self.times8(F), self.times8(H)
+        X, Y = self.side_by_side(lambda: self.mul(E, nE, F, F8, "X"), lambda: self.mul(G, nG, H, H8, "Y"))
+        Z, tt = self.side_by_side(lambda: self.mul(G, nG, F, F8, "Z"), lambda: self.mul(E, nE, H, H8, "tt"))
+        self.tighten(self.fe2_add(X, Y, "n"), 2, out=oN)
+        self.tighten(self.fe2_sub(Y, X, "d"), 2, out=oD)
+        self.tighten(self.fe2_add(Z, Z, "e"), 2, out=oE)
+        self.tighten(self.kmul(tt, two_d, "f"), 1, out=oF)
+
+
 XYZ = [("fe2", "X"), ("fe2", "Y"), ("fe2", "Z")]
 ENTRY = [("fe2", "tN"), ("fe2", "tD"), ("fe2", "tE"), ("fe2", "tF")]
 
@@ -426,11 +627,74 @@ def body_sqru():
     return b
 
 
+def _constants():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fq_constants", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "fourq_amd", "constants.py"))
+    K = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(K)
+    return K
+
+
+def _spec(*names):
+    return [("fe2", n) for n in names]
+
+
+# The table bodies work IN PLACE where a value's last read precedes the result's first write (every formula below writes its
+# results with its last products / its closing negations), which keeps their operand lists short.
+def body_tau():
+    K = _constants()
+    b = Body(_spec("X", "Y", "Z") + [("u32", "mask")])
+    b.f_tau(b.X, b.Y, b.Z, b.X, b.Y, b.Z, K.ctau)
+    return b
+
+
+def body_taudual():
+    K = _constants()
+    b = Body(_spec("X", "Y", "Z", "oN3", "oD3", "oF3") + [("u32", "mask")])
+    b.f_tau_dual(b.X, b.Y, b.Z, b.X, b.Y, b.Z, b.oN3, b.oD3, b.oF3, K.ctaudual)
+    return b
+
+
+def body_upsilon():
+    K = _constants()
+    b = Body(_spec("X", "Y", "Z") + [("u32", "mask")])
+    b.f_upsilon(b.X, b.Y, b.Z, b.X, b.Y, b.Z, K.cphi)
+    return b
+
+
+def body_chi():
+    K = _constants()
+    b = Body(_spec("X", "Y", "Z") + [("u32", "mask")])
+    b.f_chi(b.X, b.Y, b.Z, b.X, b.Y, b.Z, K.cpsi)
+    return b
+
+
+def _two_d(K):
+    return ((2 * K.d[0]) % K.P127, (2 * K.d[1]) % K.P127)
+
+
+def body_r1tor2():
+    K = _constants()
+    b = Body(_spec("oN", "oD", "oE", "oF", "X", "Y", "Z", "Ta", "Tb") + [("u32", "mask")])          # outputs first: the operand numbering of an asm statement
+    b.f_r1_to_r2(b.X, b.Y, b.Z, b.Ta, b.Tb, b.oN, b.oD, b.oE, b.oF, _two_d(K))
+    return b
+
+
+def body_tableadd():
+    K = _constants()
+    b = Body(_spec("qN", "qD", "qE", "qF", "pN", "pD", "pE", "pF") + [("u32", "mask")])       # q (the table entry) in, the new entry out, in place
+    b.f_table_add(b.pN, b.pD, b.pE, b.pF, b.qN, b.qD, b.qE, b.qF, b.qN, b.qD, b.qE, b.qF, _two_d(K))
+    return b
+
+
+TABLE_BODIES = ("TAU", "TAUDUAL", "UPSILON", "CHI", "R1TOR2", "TABLEADD")
 SMALL_BODIES, SMALL_POOL_LO = ("MULU", "SQRU"), 236          # single products: 16 temporaries, their own short clobber list
-BODIES = [("DBL", body_dbl), ("DBLT", body_dblt), ("ADD", body_add), ("STEP", body_step), ("MULU", body_mulu), ("SQRU", body_sqru)]
+BODIES = [("DBL", body_dbl), ("DBLT", body_dblt), ("ADD", body_add), ("STEP", body_step), ("MULU", body_mulu), ("SQRU", body_sqru),
+          ("TAU", body_tau), ("TAUDUAL", body_taudual), ("UPSILON", body_upsilon), ("CHI", body_chi), ("R1TOR2", body_r1tor2), ("TABLEADD", body_tableadd)]
 
 
-def allocate(prog, POOL_LO=POOL_LO):
+def allocate(prog, POOL_LO=POOL_LO, top_down=False):
     """Linear scan over the straight-line body: temporaries get physical registers POOL_LO..POOL_HI (pairs even-aligned,
     taken from the top; singles from the bottom).  A register freed by instruction i is reusable from instruction i+1."""
     def unit(x):                                          # the allocation unit of a value: itself, or its pair
@@ -444,10 +708,14 @@ def allocate(prog, POOL_LO=POOL_LO):
     free = set(range(POOL_LO, POOL_HI + 1))
     peak, pending = 0, []
 
+    lowest = [POOL_HI + 1]
+
     def take_single():
-        for r in range(POOL_LO, POOL_HI + 1):
+        order = range(POOL_HI, POOL_LO - 1, -1) if top_down else range(POOL_LO, POOL_HI + 1)
+        for r in order:
             if r in free:
                 free.discard(r)
+                lowest[0] = min(lowest[0], r)
                 return r
         raise SystemExit("out of temporaries")
 
@@ -456,6 +724,7 @@ def allocate(prog, POOL_LO=POOL_LO):
             if r in free and r + 1 in free:
                 free.discard(r)
                 free.discard(r + 1)
+                lowest[0] = min(lowest[0], r)
                 return r
         raise SystemExit("out of temporary pairs")
 
@@ -485,6 +754,7 @@ def allocate(prog, POOL_LO=POOL_LO):
                 raise SystemExit("use of %s before its definition (instruction %d)" % (x.name, idx))
             if last[id(u)] == idx:
                 pending += [u.phys, u.phys + 1] if isinstance(u, P) else [u.phys]
+    prog.lowest_register = lowest[0]
     return peak
 
 
@@ -533,7 +803,8 @@ def place(lines, mode):
         return lines
     out, off, last32 = [".p2align 3"], 0, None
     for ln in lines:
-        size = 4 if ln.split()[0].endswith("_e32") else 8
+        literal = " 0x" in ln                                   # a 32-bit literal rides behind the instruction: 8 bytes already, no _e64 form
+        size = 4 if (ln.split()[0].endswith("_e32") and not literal) else 8
         if size == 8:
             want = 0 if mode == 1 else 4
             if off % 8 != want and last32 is not None:
@@ -557,13 +828,16 @@ def main():
     pool_lo = 128 if args.variants else POOL_LO              # the experiments may use a larger pool
     for name, make in bodies:
         b = make()
-        peak = allocate(b.g, SMALL_POOL_LO if name in SMALL_BODIES else pool_lo)
+        if name in TABLE_BODIES:                                   # own clobber list, as short as the body's peak allows
+            peak = allocate(b.g, 40, top_down=True)
+        else:
+            peak = allocate(b.g, SMALL_POOL_LO if name in SMALL_BODIES else pool_lo)
         lines = place(render(b.g), b.align)
         built.append((name, b, peak, lines, collections.Counter(ln.split()[0].replace('_e64', '_e32') for ln in lines if not ln.startswith('.'))))
     if args.stats:
         for name, b, peak, lines, census in built:
             lines = [ln for ln in lines if not ln.startswith(".")]
-            print("%-5s %d instructions, %d operands, peak temporaries %d of %d" % (name, len(lines), b.n_operands, peak, POOL_HI - pool_lo + 1))
+            print("%-8s %d instructions, %d operands, peak temporaries %d (lowest register v%s)" % (name, len(lines), b.n_operands, peak, getattr(b.g, "lowest_register", "?")))
             print("      " + "  ".join("%s %d" % kv for kv in census.most_common()))
         return
     out = sys.stdout
@@ -583,6 +857,11 @@ def main():
             out.write(", \"v%d\"" % r)
         out.write("\n")
     for name, b, peak, lines, census in built:
+        if name in TABLE_BODIES:
+            out.write("#define FQ_ASM_%s_CLOBBERS \"vcc\"" % name)
+            for r in range(b.g.lowest_register, POOL_HI + 1):
+                out.write(", \"v%d\"" % r)
+            out.write("\n")
         out.write("// %s: %d instructions (%s), peak %d temporaries\n" % (name, len(lines), ", ".join("%d %s" % (v, k) for k, v in census.most_common()), peak))
         out.write("#define FQ_ASM_%s \\\n" % name)
         for ln in lines:

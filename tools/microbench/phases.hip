@@ -46,7 +46,11 @@ template <int VARIANT> __global__ __launch_bounds__(256, 1) void k(const u64* sc
     R1 P = load_r1(points + 20 * (size_t)id);
     u32* slot = scratch + (size_t)id * NDSlots::SLOT;
     uint64_t t1 = stamp();
+#if FQ_TABLE_ASM
+    if (VARIANT != 2) build_table_endo_lds_asm<NDSlots>(P, slot, ef);         // -DFQ_TABLE_ASM=1: the generated table bodies
+#else
     if (VARIANT != 2) build_table_endo_lds<NDSlots>(P, slot, ef);
+#endif
     else { for (int kk = 0; kk < 8; kk++) { R2 t = r1_to_r2(P); ef.put(kk, t); } }      // LDS filled, HBM slot left from the previous launch
     uint64_t t2 = stamp();
     u64 v[4];
