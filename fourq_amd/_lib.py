@@ -7,6 +7,15 @@ from ctypes import POINTER, c_char_p, c_int, c_size_t, c_uint8, c_uint64, c_void
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FOURQ_AMD_LIB") or os.path.join(HERE, "libfourq_amd.so")   # override: experiments only
 
+# The host-array calls keep THREE streams busy at once (copy in, kernels, copy out).  The HIP runtime maps all the streams of a process
+# onto GPU_MAX_HW_QUEUES hardware queues, 4 unless the variable says otherwise, and streams that share a queue take turns: with two
+# more streams in use elsewhere in the process (say, two torch streams) a 2^20-element MUL_endo call goes from 5.9 ms to 9.8, with four
+# more to 12.7 -- copy, kernel, copy strictly in series (profiles/r04_pipeline_queues.txt).  With 8 queues it stays at 5.9.  The runtime
+# reads the variable at its FIRST call, not when it is loaded, so a default set here -- at import, before this package has touched the
+# GPU -- still counts unless the process has already used HIP; a value the user has set is left alone.  A C host sets it in its
+# environment.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 OK, ERR_INVALID, ERR_NODEVICE, ERR_NOMEM, ERR_HIP = 0, -1, -2, -3, -4
 DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
 DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3

@@ -86,6 +86,20 @@ def test_every_environment_variable_the_library_reads_is_documented():
         assert 'route_env("%s")' % v in src and 'getenv("%s")' % v not in src, v
 
 
+def test_import_asks_for_enough_hardware_queues_and_respects_the_users_choice():
+    """the host-array pipeline needs its three streams on three hardware queues (fourq_amd/_lib.py, profiles/r04_pipeline_queues.txt):
+    importing the package sets GPU_MAX_HW_QUEUES=8 when the variable is unset and leaves a value of the user's alone"""
+    code = "import os, fourq_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    for given, want in ((None, "8"), ("2", "2"), ("16", "16")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if given is not None:
+            env["GPU_MAX_HW_QUEUES"] = given
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, check=True).stdout.strip()
+        assert out == want, (given, out)
+    for doc in ("INTEGRATION.md", "README.md", os.path.join("tools", "README.md")):
+        assert "GPU_MAX_HW_QUEUES" in open(os.path.join(ROOT, doc)).read(), doc
+
+
 def test_tuple_codec_is_fast_enough_to_be_worth_swapping_in():
     """the tuple-level API spent 4.5 + 5.6 us per element packing and unpacking in Python loops.  With
     csrc/fastcodec.c (built in-tree by build()) an R1 point + scalar packs and an R1 point unpacks in well under a microsecond on this
