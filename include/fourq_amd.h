@@ -99,7 +99,12 @@ int fourq_ctx_sync(fourq_ctx *ctx);
  * bit-identical in both modes; the price of ON is in DESIGN.md section 10.
  * Environment: FOURQ_CT_SELECT is the ONE variable the library reads as a product option.  The variables that steer batches onto
  * particular kernels (FOURQ_SPLIT_*, FOURQ_PAIR_MAX, FOURQ_QUAD_MAX, FOURQ_MIXED_QUEUE, FOURQ_NORM_K, FOURQ_BLOCKS_PER_CU,
- * FOURQ_HOST_BOUNCE, FOURQ_HOST_ZERO_COPY) are test hooks: they are ignored unless FOURQ_DEBUG_ROUTES=1 is set (tools/README.md). */
+ * FOURQ_HOST_BOUNCE, FOURQ_HOST_ZERO_COPY) are test hooks: they are ignored unless FOURQ_DEBUG_ROUTES=1 is set (tools/README.md).
+ * One variable of the HIP RUNTIME matters to the host-pointer calls: they overlap copy-in, kernels and copy-out on three streams,
+ * and the runtime shares GPU_MAX_HW_QUEUES hardware queues (default 4) among all streams the process uses -- in a process with two
+ * or more other busy streams the three stages take turns and a large call takes up to twice as long.  Set GPU_MAX_HW_QUEUES=8 in
+ * the host's environment before its first HIP call (the library does not touch the environment; the Python package sets it at
+ * import when it is unset).  The _dev calls use one stream and are not affected.  INTEGRATION.md section 3. */
 int fourq_ctx_set_ct_select(fourq_ctx *ctx, int on);
 int fourq_ctx_get_ct_select(const fourq_ctx *ctx, int *on);
 /* Resident lanes the ladder kernels are launched with (scratch is sized for this many). */

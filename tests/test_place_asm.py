@@ -1,0 +1,82 @@
+"""The build's code placement pass (tools/asmgen/place_asm.py) on hand-made gfx950 assembly: what it must do (every 8-byte instruction on an
+8-byte boundary, by re-encoding or by one s_nop in front of a long run) and the one thing it must never do (put anything between an
+s_getpc_b64 and the s_add_u32 / s_addc_u32 that follow it: their literals are computed for exactly that spacing, and a call through a
+shifted address lands four bytes in front of its target).  Needs the ROCm assembler, no GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools", "asmgen"))
+import place_asm                                   # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(place_asm.LLVM, "clang")), reason="needs the ROCm assembler")
+
+HEAD = "\t.text\n\t.amdgcn_target \"amdgcn-amd-amdhsa--gfx950\"\n"
+CALLEE = "\t.p2align 8\n\t.type g,@function\ng:\n\ts_setpc_b64 s[30:31]\n.Lfunc_end0:\n\t.size g, .Lfunc_end0-g\n"
+
+
+def func(name, body, k=1):
+    return "\t.globl %s\n\t.p2align 8\n\t.type %s,@function\n%s:\n%s.Lfunc_end%d:\n\t.size %s, .Lfunc_end%d-%s\n" % (name, name, name, body, k, name, k, name)
+
+
+def place(tmp_path, text):
+    src, dst = tmp_path / "in.s", tmp_path / "out.s"
+    src.write_text(text)
+    stats = place_asm.place_file(str(src), str(dst))
+    obj = tmp_path / "out.o"
+    place_asm.assemble(str(dst), str(obj))
+    return stats, dst.read_text(), place_asm.disassemble(str(obj))
+
+
+MADS = "".join("\tv_mad_u64_u32 v[%d:%d], vcc, v0, v1, v[%d:%d]\n" % (2 * i + 2, 2 * i + 3, 2 * i + 2, 2 * i + 3) for i in range(6))
+
+
+def test_a_call_sequence_is_left_alone(tmp_path):
+    # s_getpc_b64 at offset 0: its s_add_u32 (8 bytes) starts at 4 mod 8 with a run of 8-byte instructions behind it -- the case in which an
+    # earlier version of the pass put an s_nop between the two
+    body = "\ts_getpc_b64 s[0:1]\n\ts_add_u32 s0, s0, g@rel32@lo+4\n\ts_addc_u32 s1, s1, g@rel32@hi+12\n" + MADS + "\ts_swappc_b64 s[30:31], s[0:1]\n\ts_endpgm\n"
+    stats, text, funcs = place(tmp_path, HEAD + CALLEE + func("f", body))
+    seq = [m for m, _ in funcs["f"]]
+    k = seq.index("s_getpc_b64")
+    assert seq[k + 1:k + 3] == ["s_add_u32", "s_addc_u32"]
+    assert "s_nop" in seq[k + 3:]                  # the run of multiply-adds behind the sequence still gets its s_nop, after the s_addc_u32
+    off = 0
+    for mn, size in funcs["f"]:
+        if mn.startswith("v_mad"):
+            assert off % 8 == 0
+        off += size
+
+
+def test_a_shifted_call_sequence_is_refused(tmp_path):
+    body = "\ts_getpc_b64 s[0:1]\n\ts_nop 0\n\ts_add_u32 s0, s0, g@rel32@lo+4\n\ts_addc_u32 s1, s1, g@rel32@hi+12\n\ts_swappc_b64 s[30:31], s[0:1]\n\ts_endpgm\n"
+    src = tmp_path / "bad.s"
+    src.write_text(HEAD + CALLEE + func("f", body))
+    with pytest.raises(RuntimeError, match="s_getpc_b64 followed by"):
+        place_asm.place_file(str(src), str(tmp_path / "bad_out.s"))
+
+
+def test_misplaced_wide_instructions_are_fixed_by_reencoding_first(tmp_path):
+    body = "\tv_add_u32_e32 v0, v1, v2\n" + MADS + "\tv_add_u32_e32 v3, v1, v2\n\tv_mad_u64_u32 v[20:21], vcc, v0, v1, v[20:21]\n\ts_endpgm\n"
+    stats, text, funcs = place(tmp_path, HEAD + func("f", body, k=0))
+    assert stats["misaligned_after"] == 0 and stats["promoted"] == 2 and stats["nops"] == 0
+    assert [m for m, _ in funcs["f"]].count("v_add_u32_e64") == 2
+    assert len(funcs["f"]) == 10                   # no instruction added
+
+
+def test_the_shipped_library_keeps_every_call_sequence_intact(tmp_path):
+    """the same check on the code objects of the library the tests load"""
+    from fourq_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("library not built")
+    lib = tmp_path / "lib.so"
+    lib.write_bytes(open(_lib.LIB_PATH, "rb").read())
+    subprocess.run([os.path.join(place_asm.LLVM, "llvm-objdump"), "--offloading", str(lib)], capture_output=True, check=True, cwd=tmp_path)
+    objs = [p for p in tmp_path.iterdir() if p.name.endswith("gfx950")]
+    assert len(objs) == 4                          # one code object per translation unit
+    for o in objs:
+        place_asm.check_pc_relative(str(o))

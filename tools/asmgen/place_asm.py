@@ -8,6 +8,11 @@ device translation unit and, wherever an 8-byte instruction would start at 4 (mo
 front of it (and behind the previous 8-byte instruction) as its 8-byte _e64 form: same instruction count, same semantics, no padding.  Where
 there is no such instruction and a run of at least NOP_RUN 8-byte instructions follows, one s_nop is inserted.
 
+One place must never be touched: s_getpc_b64 and the s_add_u32 / s_addc_u32 behind it, whose literals (sym@rel32@lo+4, @hi+12) are computed
+for exactly that spacing -- an s_nop between them sends the call four bytes in front of its target (it did, in an experimental build: illegal
+instruction).  Nothing is inserted or re-encoded from an s_getpc_b64 up to the s_addc_u32 that ends the sequence, and the output object is
+checked for it (check_pc_relative).
+
     place_asm.py in.s out.s [--report]
 
 Instruction sizes are not guessed from the text: the input is assembled and disassembled (llvm-objdump prints every encoding), and the k-th
@@ -75,8 +80,7 @@ def place_function(lines, sizes, name, stats):
     # walk, tracking the offset the instruction WILL have
     out = list(lines)
     inserts = {}                                             # line index -> text to insert in front of it
-    off, last32 = 0, None
-    n = len(seq)
+    off, last32, frozen = 0, None, False
     for pos, item in enumerate(seq):
         if item[0] == "align":
             pad = (-off) % item[2]
@@ -84,6 +88,15 @@ def place_function(lines, sizes, name, stats):
             last32 = None
             continue
         _, idx, size, mn = item
+        if mn == "s_getpc_b64":                              # up to its s_addc_u32: hands off (the literals assume this exact spacing)
+            frozen, last32 = True, None
+        if frozen:
+            if size >= 8 and off % 8 == 4:
+                stats["left"] += 1
+            if mn in ("s_addc_u32", "s_setpc_b64", "s_swappc_b64"):
+                frozen = False
+            off += size
+            continue
         if size >= 8:
             if off % 8 == 4:
                 if last32 is not None:
@@ -149,11 +162,23 @@ def misaligned(obj):
     return bad, total
 
 
+def check_pc_relative(obj):
+    """every s_getpc_b64 of the object is followed at once by its s_add_u32 / s_addc_u32 pair (or, for a relaxed branch, by the label-relative
+    pair the compiler writes the same way); anything in between breaks the address arithmetic"""
+    for name, ins in disassemble(obj).items():
+        for k, (mn, _) in enumerate(ins):
+            if mn == "s_getpc_b64":
+                follow = [m for m, _ in ins[k + 1:k + 3]]
+                if follow != ["s_add_u32", "s_addc_u32"]:
+                    raise RuntimeError("%s: s_getpc_b64 followed by %s" % (name, follow))
+
+
 def place_file(src, dst, report=False):
     stats = {"promoted": 0, "nops": 0, "left": 0, "wide": 0}
     with tempfile.TemporaryDirectory() as tmp:
         obj = os.path.join(tmp, "in.o")
         assemble(src, obj)
+        check_pc_relative(obj)                               # the INPUT already deviates: do not place what is not understood
         before = misaligned(obj)
         funcs = disassemble(obj)
         with open(src) as fh:
@@ -163,6 +188,7 @@ def place_file(src, dst, report=False):
             fh.write(placed)
         obj2 = os.path.join(tmp, "out.o")
         assemble(dst, obj2)
+        check_pc_relative(obj2)
         after = misaligned(obj2)
     stats["misaligned_before"], stats["misaligned_after"], stats["wide_total"] = before[0], after[0], after[1]
     if report:
