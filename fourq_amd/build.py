@@ -21,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libfourq_amd.so")
 RESOURCES_PATH = os.path.join(HERE, "kernel_resources.json")
+PLACEMENT_PATH = os.path.join(HERE, "code_placement.json")
 # four translation units: FQ_CHAIN=0 / 1 (kernels.hip.h), and the constant-time-selection builds of both flavours
 SOURCES = ["fourq_amd.hip", "fourq_chain.hip", "fourq_ct_fused.hip", "fourq_ct_chain.hip"]
 HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "pair.hip.h", "ladder_asm.hip.h", "ladder_asm_gfx950.inc", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
@@ -181,11 +182,13 @@ def check_register_ranges(asm_path):
         raise RuntimeError("a kernel reaches an asm body whose registers it does not own:\n  " + "\n  ".join(bad))
 
 
-def compile_unit(src, obj, flags, verbose=False, place=True):
+def compile_unit(src, obj, flags, verbose=False, place=True, placement=None):
     """One translation unit -> object file; returns hipcc's remarks (the kernel resource report).  With `place`, the device code
-    takes the detour through placed assembly text described at PLACE_TOOL."""
+    takes the detour through placed assembly text described at PLACE_TOOL; `placement[src]` receives what the pass did."""
     src_path = os.path.join(SRC_DIR, src)
     if not place:
+        if placement is not None:
+            placement[src] = {"placed": False}
         return _run([_hipcc()] + flags + ["-c", "-o", obj, src_path], verbose)
     import importlib.util
     spec = importlib.util.spec_from_file_location("place_asm", PLACE_TOOL)
@@ -196,6 +199,9 @@ def compile_unit(src, obj, flags, verbose=False, place=True):
     remarks = _run([_hipcc()] + flags + ["--cuda-device-only", "-S", "-o", dev_s, src_path], verbose)
     check_register_ranges(dev_s)
     stats = place_asm.place_file(dev_s, placed_s)
+    if placement is not None:
+        placement[src] = {"placed": True, "wide_instructions": stats["wide_total"], "at_4_mod_8_before": stats["misaligned_before"],
+                          "at_4_mod_8_after": stats["misaligned_after"], "reencoded": stats["promoted"], "nops": stats["nops"]}
     if verbose:
         print("%s: %d of %d 8-byte instructions at 4 mod 8 before placement, %d after" % (
             src, stats["misaligned_before"], stats["wide_total"], stats["misaligned_after"]), file=sys.stderr)
@@ -225,16 +231,17 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
     place = "-DFQ_NO_PLACE=1" not in extra_flags
     flags = HIPCC_FLAGS + list(extra_flags) + ['-DFQ_BUILD_ID="%s"' % source_id(extra_flags)]
     objs = [os.path.join(SRC_DIR, os.path.splitext(src)[0] + suffix + ".o") for src in SOURCES]
+    placement = {}
     def one(so):
         try:
-            return compile_unit(so[0], so[1], flags, verbose, place)
+            return compile_unit(so[0], so[1], flags, verbose, place, placement)
         except RuntimeError as e:
             if not place:
                 raise
             # the placement detour failed (an assembler that rejects a re-encoding, a tool that moved): the plain hipcc build of the
             # same sources is correct, only a percent slower -- build that, and say so loudly
             print("fourq_amd.build: code placement of %s failed, building it without the pass:\n%s" % (so[0], str(e)[-1500:]), file=sys.stderr)
-            return compile_unit(so[0], so[1], flags, verbose, False)
+            return compile_unit(so[0], so[1], flags, verbose, False, placement)
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:      # the translation units in parallel (~1 min each)
         outs = list(pool.map(one, zip(SOURCES, objs)))
@@ -254,6 +261,8 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
         raise RuntimeError("link failed:\n" + proc.stdout + proc.stderr)
     with open(RESOURCES_PATH if out_path is None else lib_path + ".resources.json", "w") as fh:
         json.dump(resources, fh, indent=1, sort_keys=True)
+    with open(PLACEMENT_PATH if out_path is None else lib_path + ".placement.json", "w") as fh:      # what the placement pass did, per unit
+        json.dump(placement, fh, indent=1, sort_keys=True)
     if out_path is not None:
         for obj in objs:                                  # a variant's objects have served their purpose
             os.remove(obj)

@@ -80,3 +80,18 @@ def test_the_shipped_library_keeps_every_call_sequence_intact(tmp_path):
     assert len(objs) == 4                          # one code object per translation unit
     for o in objs:
         place_asm.check_pc_relative(str(o))
+
+
+def test_the_shipped_build_was_placed():
+    """a unit whose placement failed is built without the pass (correct, about a percent slower, fourq_amd/build.py): the build says so on
+    stderr and in fourq_amd/code_placement.json -- which must not say it of the library the tests load"""
+    import json
+    from fourq_amd import build
+    if not os.path.exists(build.PLACEMENT_PATH):
+        pytest.skip("library not built here")
+    report = json.load(open(build.PLACEMENT_PATH))
+    assert sorted(report) == sorted(build.SOURCES)
+    for unit, r in report.items():
+        assert r["placed"], unit
+        assert r["at_4_mod_8_before"] > 0.3 * r["wide_instructions"]                 # what hipcc leaves behind (39-45 %)
+        assert r["at_4_mod_8_after"] < 0.08 * r["wide_instructions"], (unit, r)      # 1-5 %: short runs behind control flow
