@@ -11,6 +11,7 @@
 // instead of a multiplication by (2,0); the constant 2d is precomputed; values that the reference
 // computes but never uses (chi's F) are not computed.
 #pragma once
+#include <type_traits>
 #include "fp127.hip.h"
 
 namespace fq {
@@ -356,12 +357,12 @@ struct LimbSlots {
     template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) { store_fe2_limbs(dst, v); }
 };
 // N and D only (the fused kernels keep E and F in LDS, kernels.hip.h LdsEF, and park table_endo's working values there too):
-// 96-byte entries, each inside two sectors, 768-byte slots: 8 192 lanes of an XCD keep 6.3 MB of entries, of which its 4 MiB L2
-// holds most.  PARK_P / PARK_Q exist for the builders that park in the slot (none does with this layout).
+// the twenty limbs of an entry back to back -- N.re, N.im, D.re, D.im -- 80 bytes = five aligned 16-byte words, 640-byte slots: the 8 192
+// lanes of an XCD keep 5.2 MB of entries against its 4 MiB of L2 (round 3's 96-byte entries, each coordinate padded to 48 bytes for its
+// own aligned loads: 6.3 MB, six loads per gather).  An entry is loaded and stored WHOLE (load_nd / store_nd below); there is no
+// per-coordinate access to this layout.  PARK_P / PARK_Q exist for the builders that park in the slot (none does with this layout).
 struct NDSlots {
-    static constexpr int COORD = COORD_U32, ENTRY = 2 * COORD_U32, PARK_P = 0, PARK_Q = 0, SLOT = 8 * 2 * COORD_U32;
-    template <typename P> static FQ_DEV Fe2<1> load(const P* src) { return load_fe2_limbs(src); }
-    template <typename P> static FQ_DEV void store(P* dst, const Fe2<1>& v) { store_fe2_limbs(dst, v); }
+    static constexpr int COORD = 10, ENTRY = 20, PARK_P = 0, PARK_Q = 0, SLOT = 8 * 20;
 };
 // tight limbs (after fe_carry) -> one 128-bit word: fold bits >= 127 (2^127 == 1), ripple once, concatenate
 FQ_DEV uint4 fe_pack128(const Fe<1>& a) {
@@ -401,12 +402,39 @@ template <typename L, typename P> FQ_DEV void store_r2(P* dst, const R2& t) {
     L::store(dst, t.N); L::store(dst + L::COORD, t.D); L::store(dst + 2 * L::COORD, t.E); L::store(dst + 3 * L::COORD, t.F);
 }
 
+// N and D of one entry, whatever the layout: coordinate by coordinate where the layout has coordinates, five 16-byte words for NDSlots
+template <typename L, typename P> FQ_DEV void load_nd(const P* entry, Fe2<1>& N, Fe2<1>& D) {
+    if constexpr (std::is_same<L, NDSlots>::value) {
+        const uint4* q = reinterpret_cast<const uint4*>(entry);
+        const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+        N.re.l[0] = a.x; N.re.l[1] = a.y; N.re.l[2] = a.z; N.re.l[3] = a.w; N.re.l[4] = b.x;
+        N.im.l[0] = b.y; N.im.l[1] = b.z; N.im.l[2] = b.w; N.im.l[3] = c.x; N.im.l[4] = c.y;
+        D.re.l[0] = c.z; D.re.l[1] = c.w; D.re.l[2] = d.x; D.re.l[3] = d.y; D.re.l[4] = d.z;
+        D.im.l[0] = d.w; D.im.l[1] = e.x; D.im.l[2] = e.y; D.im.l[3] = e.z; D.im.l[4] = e.w;
+    } else {
+        N = L::load(entry); D = L::load(entry + L::COORD);
+    }
+}
+template <typename L, typename P> FQ_DEV void store_nd(P* entry, const Fe2<1>& N, const Fe2<1>& D) {
+    if constexpr (std::is_same<L, NDSlots>::value) {
+        uint4* q = reinterpret_cast<uint4*>(entry);
+        q[0] = make_uint4(N.re.l[0], N.re.l[1], N.re.l[2], N.re.l[3]);
+        q[1] = make_uint4(N.re.l[4], N.im.l[0], N.im.l[1], N.im.l[2]);
+        q[2] = make_uint4(N.im.l[3], N.im.l[4], D.re.l[0], D.re.l[1]);
+        q[3] = make_uint4(D.re.l[2], D.re.l[3], D.re.l[4], D.im.l[0]);
+        q[4] = make_uint4(D.im.l[1], D.im.l[2], D.im.l[3], D.im.l[4]);
+    } else {
+        L::store(entry, N); L::store(entry + L::COORD, D);
+    }
+}
+
 // N and D of +-T for a table entry T: R2neg(T) = (D, N, E, -F) (curve4q.py:193-206).  Both coordinates are read from
 // their own addresses whatever the sign is and exchanged by masked selects -- GFp2.select of fields.py:236-238, one
 // v_bitop3_b32 per limb -- exactly as the reference's selectpt does: the sign of a digit never becomes an address.
 // (Round 2 chose by address; the A/B of the two is profiles/r03_sign_select.txt, the switch tools/experiments/r03_sign_by_address.patch.)
-template <typename LOAD> FQ_DEV void load_signed_nd(LOAD load, int coord, u32 neg_mask, Fe2<1>& N, Fe2<1>& D) {
-    const Fe2<1> n = load(0), d = load(coord);
+template <typename L, typename P> FQ_DEV void load_signed_nd(const P* entry, u32 neg_mask, Fe2<1>& N, Fe2<1>& D) {
+    Fe2<1> n, d;
+    load_nd<L>(entry, n, d);
     N = fe2_bitselect(neg_mask, d, n);
     D = fe2_bitselect(neg_mask, n, d);
 }
@@ -425,7 +453,7 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename L = LimbSlots, typename P> 
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
     Fe2<1> tN, tD;
-    load_signed_nd([&](int off) { return L::load(entry + off); }, L::COORD, neg_mask, tN, tD);
+    load_signed_nd<L>(entry, neg_mask, tN, tD);
     Fe2<1> A = fe2_mulx<CH>(D1, tD);                               // ADD_core: curve4q.py:155-171
     Fe2<1> B = fe2_mulx<CH>(N1, tN);
     Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(L::load(entry + 3 * L::COORD), neg_mask), T);
@@ -451,7 +479,7 @@ struct EntryRegs {
 template <typename L = LimbSlots, typename P, typename EF> FQ_DEV EntryRegs load_entry(const P* entry, u32 neg_mask, u32 digit, const EF& ef) {
     EntryRegs t;
     (void)neg_mask;
-    t.N = L::load(entry); t.D = L::load(entry + L::COORD);          // the sign is applied by add_entry, behind the doubling
+    load_nd<L>(entry, t.N, t.D);                                    // the sign is applied by add_entry, behind the doubling
     if constexpr (EF::ON) {
         t.E = ef.get(digit, 0); t.F = ef.get(digit, 1);
     } else {
@@ -503,7 +531,7 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_affine_tab
     Fe2<2> N1 = fe2_add(q.X, q.Y);
     Fe2<3> D1 = fe2_subx<CH>(q.Y, q.X);
     Fe2<1> tN, tD;
-    load_signed_nd([&](int off) { return load_fe2_limbs(entry + off); }, COORD_U32, neg_mask, tN, tD);
+    load_signed_nd<LimbSlots>(entry, neg_mask, tN, tD);
     Fe2<1> A = fe2_mulx<CH>(D1, tD);
     Fe2<1> B = fe2_mulx<CH>(N1, tN);
     Fe2<1> C = fe2_mulx<CH>(fe2_cnegx<CH>(load_fe2_limbs(entry + 2 * COORD_U32), neg_mask), T);
@@ -529,7 +557,7 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, typename P> FQ_DEV R1 add_affine_tab
 // the comb's starting point: +-A as an R1 point (Z = 1)
 template <typename P> FQ_DEV R1 affine_table_start(const P* entry, u32 neg_mask) {
     Fe2<1> N, D;                                                                     // x+y, y-x of +-A
-    load_signed_nd([&](int off) { return load_fe2_limbs(entry + off); }, COORD_U32, neg_mask, N, D);
+    load_signed_nd<LimbSlots>(entry, neg_mask, N, D);
     // x = (N - D)/2, y = (N + D)/2: keep the factor 2 projectively: (X, Y, Z) = (N - D, N + D, 2)
     R1 r;
     r.X = fe2_carry(fe2_sub(N, D));
@@ -638,11 +666,12 @@ template <typename EFT> struct ScanSplit {
     template <typename L, typename TP> FQ_DEV void load(const TP* tbl) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
+            Fe2<1> v[2];
+            load_nd<L>(tbl + k * L::ENTRY, v[0], v[1]);
 #pragma unroll
             for (int c = 0; c < 2; c++) {
-                const Fe2<1> v = L::load(tbl + k * L::ENTRY + c * L::COORD);
 #pragma unroll
-                for (int i = 0; i < 5; i++) { nd[k][c * 10 + i] = v.re.l[i]; nd[k][c * 10 + 5 + i] = v.im.l[i]; }
+                for (int i = 0; i < 5; i++) { nd[k][c * 10 + i] = v[c].re.l[i]; nd[k][c * 10 + 5 + i] = v[c].im.l[i]; }
             }
         }
     }
@@ -749,11 +778,12 @@ template <typename SRC> FQ_DEV R1 affine_scan_start(const SRC& src, u32 idx_valu
 // R2toR4(selectpt(s, T, nT)): the ladder's starting point (curve4q.py:229, :437)
 template <typename L = LimbSlots, typename P> FQ_DEV Proj<1, 1, 1> start_table(const P* entry, u32 neg_mask) {
     Fe2<1> N, D;
-    load_signed_nd([&](int off) { return L::load(entry + off); }, L::COORD, neg_mask, N, D);
+    load_signed_nd<L>(entry, neg_mask, N, D);
     Proj<1, 1, 1> r;
     r.X = fe2_carry(fe2_sub(N, D));
     r.Y = fe2_carry(fe2_add(D, N));
-    r.Z = L::load(entry + 2 * L::COORD);
+    if constexpr (std::is_same<L, NDSlots>::value) r.Z = Fe2<1>{};      // E lives in LDS with this layout: the caller takes it from there
+    else r.Z = L::load(entry + 2 * L::COORD);
     return r;
 }
 

@@ -76,7 +76,7 @@ struct NoEF {
 // entry k of a lane's table: with an LdsEF only N and D go to (come from) the HBM slot, E and F live in LDS alone
 template <typename L, typename EF> FQ_DEV void store_entry(u32* slot, int k, const R2& t, const EF& ef) {
     if constexpr (EF::ON) {
-        L::store(slot + k * L::ENTRY, t.N); L::store(slot + k * L::ENTRY + L::COORD, t.D);
+        store_nd<L>(slot + k * L::ENTRY, t.N, t.D);
         ef.put(k, t);
     } else {
         store_r2<L>(slot + k * L::ENTRY, t);
@@ -85,7 +85,7 @@ template <typename L, typename EF> FQ_DEV void store_entry(u32* slot, int k, con
 template <typename L, typename EF> FQ_DEV R2 load_entry_r2(const u32* slot, int k, const EF& ef) {
     if constexpr (EF::ON) {
         R2 t;
-        t.N = L::load(slot + k * L::ENTRY); t.D = L::load(slot + k * L::ENTRY + L::COORD);
+        load_nd<L>(slot + k * L::ENTRY, t.N, t.D);
         t.E = ef.get((u32)k, 0); t.F = ef.get((u32)k, 1);
         return t;
     } else {
