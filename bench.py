@@ -59,11 +59,11 @@ WORKLOADS = {
                       "(first half fixed-base through the 1024-point comb of [392]G, same affine outputs as with table_endo([392]G); "
                       "second half variable-base); affine in/out"),
     "cfg5": dict(batch=1 << 17, steps=300, bytes=(192 + 352) // 2, alg_mads=(41_984 + 49_440) // 2, mads=(83_300 + 97_600) // 2, seed=50002,
-                 kernel="partition_kernel + prep_kernel<ENDO> + ladder_kernel<ENDO, PREBUILT> with a per-lane table pointer (asm ladder bodies, two waves per SIMD)",
+                 kernel="partition_kernel + mixed_queue_kernel (one persistent kernel, one wave per SIMD pulling 64-element work items off a device-side queue: fused table_endo + asm ladder for variable-base items, the shared table for fixed-base ones)",
                  unit="MUL_endo, 50% fixed base / 50% variable base",
                  text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo; "
-                      "device-side compaction of the variable-base ids, their tables built by prep_kernel, then ONE pointer-selected "
-                      "ladder launch per round (DESIGN.md section 5)"),
+                      "device-side compaction of the ids of both kinds, then BASELINE's own mechanism: a single persistent kernel whose waves "
+                      "pull work items from a device-side queue (DESIGN.md section 5)"),
 }
 RANK_SEED_STRIDE = 16        # rank r draws from seed + 16 r (rank 0 = the seeds of SURVEY.md 8d)
 

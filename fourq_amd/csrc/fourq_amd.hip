@@ -549,7 +549,11 @@ template <int ALGO, bool DH> int launch_variable(fourq_ctx* c, LadderArgs a) {
 // elements: 0.39 ms against 0.42, constant-time mode 0.48 against 0.81).  Past that the queue hands a wave a third item as soon
 // as the kinds do not split evenly -- BASELINE config 5's 65 550 variable-base elements of 2^17: 0.88 ms against 0.65 -- where the
 // two-kernel route's ladder still has three free wave slots per SIMD.  FOURQ_MIXED_QUEUE=0|1 forces either.
-bool mixed_queue_default(const fourq_ctx* c, size_t round) { return round <= c->lanes; }
+// Mixed rounds through the persistent work-queue kernel (BASELINE config 5's mechanism): every round in the default mode -- since its items
+// run over the two lists laid end to end it beats compaction + prep + pointer-selected ladder at every size (config 5: 0.609 against 0.630 ms,
+// 2^20 elements 4.40 against 4.53, profiles/r04_mixed_queue.txt) -- and rounds of at most one generation in constant-time mode, where the
+// fused kernel + mixed_ct_tail_kernel pair is as fast for larger ones (0.800 both).
+bool mixed_queue_default(const fourq_ctx* c, size_t round) { return !c->ct || round <= c->lanes; }
 
 // DH outputs are affine: from two resident generations of lanes upwards each lane meets several elements, and
 // the inversions of K of them are merged into one (normalize_kernel).  Returns K (0: invert per element).
@@ -1181,10 +1185,11 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
         a.scalars = s; a.points = p; a.out = o; a.n = (u32)n; a.flags = flags;
         return launch_pair_mixed(c, a);
     }
-    // Rounds of up to split_chunk elements.  Per round: compact the variable-base ids (count stays on the device),
-    // build their tables into scratch slots (prep_kernel over the compacted list), then ONE ladder launch over all
-    // elements of the round in their natural order: each lane reads its table through a pointer -- its own slot or
-    // the shared fixed-base table -- so fixed and variable elements share wavefronts without divergence.
+    // Rounds of up to split_chunk elements.  Per round: compact the ids of both kinds (counts stay on the device), then -- the default --
+    // ONE persistent kernel whose waves pull 64-element work items off a device-side queue (mixed_queue_kernel), or, behind the test hook
+    // FOURQ_MIXED_QUEUE=0, round 2's route: the variable-base ids' tables built into scratch slots (prep_kernel over the compacted list)
+    // and ONE ladder launch over all elements of the round in their natural order, each lane reading its table through a pointer -- its
+    // own slot or the shared fixed-base table -- so that fixed and variable elements share wavefronts without divergence.
     const size_t per_block = (size_t)BLOCK * PART_PER_LANE;
     for (size_t off = 0; off < n; off += c->split_chunk) {
         const u32 m = (u32)(n - off < c->split_chunk ? n - off : c->split_chunk);
@@ -1199,7 +1204,7 @@ FQ_API int fourq_mul_endo_mixed_batch_dev(fourq_ctx* c, const uint64_t* s, const
         if (queue) {
             // BASELINE config 5's mechanism: one persistent kernel, one block per CU, every wave pulling 64-element work items
             // (variable-base first) from a device-side queue until it is empty (kernels.hip.h, mixed_queue_kernel)
-            const size_t items = ((size_t)m + 63) / 64 + 1, blocks = (items + 3) / 4;
+            const size_t items = ((size_t)m + 63) / 64, blocks = (items + 3) / 4;
             const unsigned grid = (unsigned)(blocks < (size_t)c->cus ? blocks : (size_t)c->cus);
             if (c->ct) {
                 HIPRC_TRY(c, ct_launch_mixed_queue(grid, c->stream, a, c->part_list, c->part_fix, c->part_counter, c->part_counter + 2));

@@ -27,7 +27,7 @@ constexpr int SLOT_U32 = LimbSlots::SLOT;   // a whole-entry scratch slot (table
 // Layout of the slots that prep_kernel fills and ladder_kernel<PREBUILT> gathers from: 2^18 elements in flight make
 // 486 MB of 192-byte entries, past the 256 MiB Infinity Cache, and the DH ladder of BASELINE config 4 then pulled
 // 4 TB/s from HBM; packed 128-byte entries cut that by a third and let a round's tables stay in the cache.
-// (The fused kernels keep ready-to-use limbs: N, D in compact NDSlots -- 2^16 slots = 50 MB, inside the Infinity Cache --
+// (The fused kernels keep ready-to-use limbs: N, D in dense NDSlots -- 2^16 slots = 42 MB, inside the Infinity Cache --
 // and E, F in LDS, below.)
 typedef PackedSlots PrebuiltSlots;
 constexpr int PROJ_PLANES = 8;            // deferred normalisation: the 30 working limbs of (X, Y, Z) in eight uint4 planes
@@ -804,20 +804,23 @@ __global__ __launch_bounds__(BLOCK, 1) void pair_kernel(LadderArgs a) {
 
 // ---- mixed batches: ONE persistent kernel pulling work from a device-side queue (BASELINE config 5) ----------------
 // partition_kernel has compacted the ids of the round's variable-base and fixed-base elements (counts[0], counts[1]).  A work
-// item is 64 elements of one kind; items [0, var_items) are variable-base (fused table_endo + ladder, as ladder_kernel<ENDO,
-// FUSED>), the rest fixed-base (the shared table, gathered through L1 a doubling ahead).  One block per CU owns the CU's LDS
-// (E, F of the lanes' tables) and a scratch slot per lane; each of its four waves loops on its own: take the next item with
-// one atomic, run it, until the queue is empty.  The kind of an item is wave-uniform, so no wave ever diverges, the long
-// items are handed out first, and 65 550 variable-base elements cost one extra item on one SIMD instead of a generation of the
-// whole chip.  CT: constant-time table selection for both kinds (the kind of an element is public, its digits are not).
-// Every wave leaves the loop: the queue head only grows and `total` is fixed before the launch.
+// item is 64 consecutive positions of the two lists laid end to end, variable-base first: items wholly inside the first list are
+// variable-base (fused table_endo + ladder, as ladder_kernel<ENDO, FUSED>), items wholly inside the second fixed-base (the shared
+// table, gathered through L1 a doubling ahead), and the ONE item that straddles the boundary runs as a variable-base item whose
+// fixed-base lanes copy the shared table into their own slot and LDS rows instead of building one -- so 65 550 + 65 522 elements
+// are 2 048 items, two per resident wave, not 1 025 + 1 024 with a third item (a whole ladder) for one wave (round 3's version:
+// profiles/r03_mixed_queue.txt).  One block per CU owns the CU's LDS (E, F of the lanes' tables) and a scratch slot per lane; each
+// of its four waves loops on its own: take the next item with one atomic, run it, until the queue is empty.  Except in the
+// boundary item no wave diverges, and the long items are handed out first.  CT: constant-time table selection for both kinds
+// (the kind of an element is public, its digits are not).  Every wave leaves the loop: the queue head only grows and `total` is
+// fixed before the launch.
 template <bool CT>
 __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, const u32* var_list, const u32* fix_list, const u32* counts, u32* queue_head) {
     __shared__ __attribute__((aligned(16))) u32 lds_ef[EF_LDS_U32];
     LdsEF ef;
     ef.lane = reinterpret_cast<uint2*>(lds_ef) + threadIdx.x;
-    const u32 n_var = counts[0], n_fix = counts[1];
-    const u32 var_items = (n_var + 63) / 64, total = var_items + (n_fix + 63) / 64;
+    const u32 n_var = counts[0], n_all = n_var + counts[1];
+    const u32 total = (n_all + 63) / 64;
     u32* slot = a.scratch + (size_t)(blockIdx.x * BLOCK + threadIdx.x) * NDSlots::SLOT;
     const u32 lane = threadIdx.x & 63;
     constexpr int CH = (FQ_LADDER_ASM && (!CT || FQ_CT_FUSED_ASM)) ? 3 : LADDER_CH;
@@ -827,18 +830,24 @@ __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, con
         if (lane == 0) item = atomicAdd(queue_head, 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= total) break;
-        const bool variable = item < var_items;                     // wave-uniform
-        const u32 count = variable ? n_var : n_fix;
-        const u32 pos = (variable ? item : item - var_items) * 64 + lane;
-        const bool live = pos < count;
-        const u32 id = (variable ? var_list : fix_list)[live ? pos : count - 1];   // idle tail lanes redo the last element, store nothing
+        const u32 first = item * 64;
+        const bool all_fixed = first >= n_var;                      // wave-uniform
+        const bool live = first + lane < n_all;
+        const u32 pos = live ? first + lane : n_all - 1;            // idle tail lanes redo the last element, store nothing
+        const bool variable = pos < n_var;                          // per lane: differs inside the wave in the boundary item only
+        const u32 id = variable ? var_list[pos] : fix_list[pos - n_var];
         u64 m[4];
         load_scalar(a.scalars + 4 * (size_t)id, m);
         R1 Q;
-        if (variable) {
-            const R1 P = load_r1(a.points + 20 * (size_t)id);
-            if constexpr (FQ_TABLE_ASM && FQ_LADDER_ASM) build_table_endo_lds_asm<NDSlots>(P, slot, ef);
-            else build_table_endo_lds<NDSlots>(P, slot, ef);
+        if (!all_fixed) {
+            if (variable) {
+                const R1 P = load_r1(a.points + 20 * (size_t)id);
+                if constexpr (FQ_TABLE_ASM && FQ_LADDER_ASM) build_table_endo_lds_asm<NDSlots>(P, slot, ef);
+                else build_table_endo_lds<NDSlots>(P, slot, ef);
+            } else {                                                // a fixed-base lane of the boundary item: the shared table as its own
+#pragma unroll 1
+                for (int k = 0; k < 8; k++) store_entry<NDSlots>(slot, k, load_r2_limbs(a.table + k * R2_LIMBS), ef);
+            }
             u64 v[4];
             decompose(m, v);
             const EndoDigits e = recode(v);
