@@ -10,4 +10,6 @@ from ._lib import FourQError  # noqa: F401
 from .engine import Engine, default_engine  # noqa: F401
 from .multi import MultiEngine, device_count  # noqa: F401
 
-__version__ = "0.3.0"
+from ._lib import ABI_VERSION as _ABI
+
+__version__ = "%d.%d.%d" % (_ABI // 10000, (_ABI // 100) % 100, _ABI % 100)   # = fourq_version() of the library this package binds (10000*major + 100*minor + patch)

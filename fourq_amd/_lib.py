@@ -150,8 +150,31 @@ def load():
     if lib.fourq_version() != ABI_VERSION:       # e.g. a library built before the comb table grew: its buffers would not match ours
         raise FourQError("%s is version %d, this package expects %d: rebuild it (`python -m fourq_amd.build --force`)"
                          % (LIB_PATH, lib.fourq_version(), ABI_VERSION))
+    _warn_if_not_built_from_these_sources(lib)
     _lib = lib
     return lib
+
+
+def build_matches_sources(lib=None):
+    """True when the loaded library was compiled from the sources beside it (fourq_build_id() == build.source_id()), False when it
+    was not, None when that cannot be told (an experiment library named by FOURQ_AMD_LIB, or a tree without its csrc/)."""
+    if os.environ.get("FOURQ_AMD_LIB"):
+        return None
+    try:
+        from .build import source_id
+        want = source_id()
+    except OSError:
+        return None
+    return (lib or load()).fourq_build_id().decode() == want
+
+
+def _warn_if_not_built_from_these_sources(lib):
+    # is_stale() goes by mtimes, which a checkout or a copy to the GPU box rewrites; the id compiled into the library is a hash of the
+    # translation units, headers and flags, so it says for certain whether what will be tested and timed is what the sources say
+    if build_matches_sources(lib) is False:
+        import warnings
+        warnings.warn("%s (build %s) was not compiled from the sources in %s: run `python -m fourq_amd.build` -- results and timings "
+                      "below are those of the OLD code" % (LIB_PATH, lib.fourq_build_id().decode(), os.path.join(HERE, "csrc")), RuntimeWarning, stacklevel=3)
 
 
 def check(rc, ctx=None):

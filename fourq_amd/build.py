@@ -150,12 +150,21 @@ def _run(cmd, verbose=False):
     return proc.stdout
 
 
+class RegisterOwnershipError(Exception):
+    """A kernel reaches a hand-scheduled body whose physical registers lie outside its allocation.  NOT a RuntimeError on purpose: the
+    build's fallback for a failed placement detour catches RuntimeError, and this finding must never be swallowed by it -- the plain
+    hipcc build of the same sources would carry the same kernel."""
+
+
 def check_register_ranges(asm_path):
     """The generated bodies (ladder_asm.hip.h) name their temporaries as PHYSICAL registers (v168-v255, v236-v255) and declare them as
     clobbers.  hipcc counts clobbered registers into a kernel's allocation -- unless the kernel's launch bounds cap its budget below them, in
     which case it only warns ("reserved registers") and the instruction would address registers the wave does not own.  No such kernel may
-    reach a body: every kernel's highest VGPR named in its code must lie inside its `.amdhsa_next_free_vgpr`."""
-    kernel, highest, alloc = None, {}, {}
+    reach a body: every kernel's highest VGPR named in its code must lie inside its ARCHITECTURAL VGPR allocation.  On gfx950
+    `.amdhsa_next_free_vgpr` is the unified VGPR + AGPR total; where a kernel has AGPRs, `.amdhsa_accum_offset` is where they begin, i.e.
+    the number of arch VGPRs (a v236 named by a kernel with accum_offset 176 would alias its AGPRs and still be below next_free_vgpr).
+    A kernel that names VGPRs but has no parsable allocation fails too."""
+    kernel, highest, alloc, accum = None, {}, {}, {}
     with open(asm_path) as fh:
         for ln in fh:
             m = re.match(r"^(_Z\w+):", ln)
@@ -170,6 +179,10 @@ def check_register_ranges(asm_path):
             if m and kernel:
                 alloc[kernel] = int(m.group(1))
                 continue
+            m = re.match(r"\s*\.amdhsa_accum_offset\s+(\d+)", ln)
+            if m and kernel:
+                accum[kernel] = int(m.group(1))
+                continue
             t = ln.strip()
             if kernel is None or not t or t[0] in ";.":
                 continue
@@ -177,24 +190,42 @@ def check_register_ranges(asm_path):
                 r = int(a or b)
                 if r > highest.get(kernel, -1):
                     highest[kernel] = r
-    bad = ["%s names v%d but owns %d VGPRs" % (k, h, alloc[k]) for k, h in highest.items() if k in alloc and h >= alloc[k]]
+    bad = []
+    for k, h in highest.items():
+        if k not in alloc:
+            # device functions that are not kernels have no descriptor; only entry points (.amdhsa_kernel) are checked
+            continue
+        owned = min(alloc[k], accum.get(k, alloc[k]))      # accum_offset < next_free_vgpr  <=>  the kernel has AGPRs above its arch VGPRs
+        if h >= owned:
+            bad.append("%s names v%d but owns %d arch VGPRs (next_free_vgpr %d, accum_offset %s)" % (k, h, owned, alloc[k], accum.get(k, "-")))
+    if not alloc and highest:
+        bad.append("%s: VGPRs are named but no .amdhsa_next_free_vgpr could be parsed -- the listing format changed" % asm_path)
     if bad:
-        raise RuntimeError("a kernel reaches an asm body whose registers it does not own:\n  " + "\n  ".join(bad))
+        raise RegisterOwnershipError("a kernel reaches an asm body whose registers it does not own:\n  " + "\n  ".join(bad))
 
 
 def compile_unit(src, obj, flags, verbose=False, place=True, placement=None):
     """One translation unit -> object file; returns hipcc's remarks (the kernel resource report).  With `place`, the device code
     takes the detour through placed assembly text described at PLACE_TOOL; `placement[src]` receives what the pass did."""
     src_path = os.path.join(SRC_DIR, src)
+    stem = os.path.splitext(obj)[0]
     if not place:
         if placement is not None:
             placement[src] = {"placed": False}
+        # the register-ownership check reads the device listing, so the unplaced build makes one too (ADVICE r4: the fallback and the
+        # -DFQ_NO_PLACE=1 variants used to skip the check); the object itself comes from the ordinary one-step compile
+        listing = stem + ".check.s"
+        try:
+            _run([_hipcc()] + [f for f in flags if not f.startswith("-Rpass")] + ["--cuda-device-only", "-S", "-o", listing, src_path], verbose)
+            check_register_ranges(listing)
+        finally:
+            if os.path.exists(listing):
+                os.remove(listing)
         return _run([_hipcc()] + flags + ["-c", "-o", obj, src_path], verbose)
     import importlib.util
     spec = importlib.util.spec_from_file_location("place_asm", PLACE_TOOL)
     place_asm = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(place_asm)
-    stem = os.path.splitext(obj)[0]
     dev_s, placed_s, dev_o, hsaco, fatbin = stem + ".dev.s", stem + ".placed.s", stem + ".dev.o", stem + ".hsaco", stem + ".hipfb"
     remarks = _run([_hipcc()] + flags + ["--cuda-device-only", "-S", "-o", dev_s, src_path], verbose)
     check_register_ranges(dev_s)
@@ -222,7 +253,12 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
     resource report goes to <out_path>.resources.json and is not policy-checked.  The pseudo-flag -DFQ_NO_PLACE=1 builds a
     variant without the code placement pass."""
     if out_path is None:
-        build_fastcodec(force, verbose)
+        try:
+            build_fastcodec(force, verbose)
+        except Exception as exc:            # optional: codec.py has a pure-Python path.  A host without gcc, or a CPython whose int
+            #                                 internals fastcodec.c does not know, must not stop the GPU library from being built
+            print("fourq_amd.build: WARNING -- the tuple codec extension (csrc/fastcodec.c) did not build; fourq_amd.codec falls back to "
+                  "its pure-Python conversions (~5 us per element instead of ~0.5):\n%s" % str(exc)[-1500:], file=sys.stderr)
     if out_path is None and not force and not is_stale():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
@@ -239,7 +275,8 @@ def build_library(force=False, verbose=False, extra_flags=(), out_path=None):
             if not place:
                 raise
             # the placement detour failed (an assembler that rejects a re-encoding, a tool that moved): the plain hipcc build of the
-            # same sources is correct, only a percent slower -- build that, and say so loudly
+            # same sources is correct, only a percent slower -- build that, and say so loudly.  A RegisterOwnershipError is not a
+            # RuntimeError and passes straight through: it is a finding about the kernel, not about the detour
             print("fourq_amd.build: code placement of %s failed, building it without the pass:\n%s" % (so[0], str(e)[-1500:]), file=sys.stderr)
             return compile_unit(so[0], so[1], flags, verbose, False, placement)
 

@@ -13,16 +13,18 @@ waiter, which runs the next batch -- so no caller is held back working for other
 Invariants (all under `_lock`): `_busy` is False only while `_queue` is empty; the queue holds exactly the calls no batch has
 taken yet, oldest first; the leader's own call is `_queue[0]` when it takes its batch (it either found the queue empty or
 was promoted as the oldest waiter), so a leader is always served by its own batch; every slot's event is set exactly once,
-either with `done` (served) or without (promoted); a waiter that leaves by an exception takes its slot out of the queue (`_abandon`).
+either with `done` (served) or without (promoted); `promoted` is set UNDER THE LOCK when an heir is chosen -- the event is set after
+the lock is released, so the flag, not the event, is what says "leadership was handed to this slot"; a waiter that leaves by an
+exception takes its slot out of the queue and, if it had been promoted, hands the leadership on (`_abandon`).
 """
 import threading
 
 
 class _Slot:
-    __slots__ = ("args", "result", "error", "done", "event")
+    __slots__ = ("args", "result", "error", "done", "promoted", "event")
 
     def __init__(self, args):
-        self.args, self.result, self.error, self.done = args, None, None, False
+        self.args, self.result, self.error, self.done, self.promoted = args, None, None, False, False
         self.event = threading.Event()
 
 
@@ -74,9 +76,7 @@ class Combiner:
                 self.calls += len(batch)
                 self.batches += 1
                 self.largest = max(self.largest, len(batch))
-                heir = self._queue[0] if self._queue else None
-                if heir is None:
-                    self._busy = False
+                heir = self._pick_heir()
             for s in batch:
                 s.done = True
                 if s is not slot:
@@ -87,19 +87,26 @@ class Combiner:
 
     def _abandon(self, slot):
         """A waiter leaves without its result.  Still queued: it is taken out, so that it can never be picked as the next leader (a
-        batch nobody runs would leave `_busy` set and block every later caller).  Already promoted (its event set, not served): the
+        batch nobody runs would leave `_busy` set and block every later caller).  Already promoted (chosen as heir, not served): the
         leadership it was handed goes on to the oldest waiter, or is given up.  Already in a running batch: nothing to undo."""
         heir = None
         with self._lock:
             if slot in self._queue:
-                promoted = slot.event.is_set() and not slot.done
+                # `promoted`, not `event.is_set()`: the leader picks its heir under the lock and sets the event after releasing it, and
+                # an interrupt in that window must still pass the leadership on (ADVICE r4)
                 self._queue.remove(slot)
-                if promoted:
-                    heir = self._queue[0] if self._queue else None
-                    if heir is None:
-                        self._busy = False
+                if slot.promoted:
+                    heir = self._pick_heir()
         if heir is not None:
             heir.event.set()
+
+    def _pick_heir(self):
+        """Under the lock: the oldest waiter becomes the next leader (marked `promoted`), or, with nobody waiting, the GPU is free."""
+        if self._queue:
+            self._queue[0].promoted = True
+            return self._queue[0]
+        self._busy = False
+        return None
 
     @staticmethod
     def _finish(slot):

@@ -14,16 +14,52 @@
 #include <stdint.h>
 #include <string.h>
 
+/* CPython's int internals changed in 3.12 (ob_digit moved, Py_SIZE no longer the sign) and _PyLong_AsByteArray grew an argument in
+ * 3.13.  The direct-digit paths below are for 3.10 / 3.11, the interpreters of this image and the only ones these lines have been run
+ * on; later versions compile the documented byte-array calls instead (PyLong_AsNativeBytes / PyLong_FromUnsignedNativeBytes from 3.13).
+ * If neither compiles, fourq_amd/build.py warns and fourq_amd/codec.py keeps its pure-Python path. */
+#if PY_VERSION_HEX < 0x030C0000
+#define FQ_DIRECT_DIGITS 1
+#else
+#define FQ_DIRECT_DIGITS 0
+#endif
+
 static int int_to_le(PyObject* v, unsigned char* dst, size_t width) {
     if (!PyLong_Check(v)) {
         PyErr_SetString(PyExc_TypeError, "expected an int");
         return -1;
     }
+#if PY_VERSION_HEX >= 0x030D0000
+    Py_ssize_t need = PyLong_AsNativeBytes(v, dst, (Py_ssize_t)width,
+                                           Py_ASNATIVEBYTES_LITTLE_ENDIAN | Py_ASNATIVEBYTES_UNSIGNED_BUFFER | Py_ASNATIVEBYTES_REJECT_NEGATIVE);
+    if (need < 0) {                                        /* negative value: ValueError there, OverflowError for our callers */
+        PyErr_Clear();
+        PyErr_SetString(PyExc_OverflowError, "negative value");
+        return -1;
+    }
+    if ((size_t)need > width) {
+        PyErr_SetString(PyExc_OverflowError, "int too big to convert");
+        return -1;
+    }
+    return 0;
+#else
+#if FQ_DIRECT_DIGITS
     if (Py_SIZE(v) < 0) {                                  /* negative: the caller reduces */
         PyErr_SetString(PyExc_OverflowError, "negative value");
         return -1;
     }
+#endif
+    /* unsigned conversion: a negative value raises OverflowError here as well */
     return _PyLong_AsByteArray((PyLongObject*)v, dst, width, 1 /* little endian */, 0 /* unsigned */);
+#endif
+}
+
+static PyObject* long_from_le(const unsigned char* src, size_t width) {
+#if PY_VERSION_HEX >= 0x030D0000
+    return PyLong_FromUnsignedNativeBytes(src, width, Py_ASNATIVEBYTES_LITTLE_ENDIAN);
+#else
+    return _PyLong_FromByteArray(src, width, 1, 0);
+#endif
 }
 
 /* A GF(p) value, p = 2^127 - 1: any int in [0, 2^128) is stored as its residue in [0, p), as the reference's `% p1271` leaves it. */
@@ -47,7 +83,7 @@ static int fp_to_le(PyObject* v, unsigned char* dst) {
 
 /* 16 little-endian bytes -> int.  With 30-bit digits (every 64-bit CPython) the five digits are written directly. */
 static PyObject* long_from_le16(const unsigned char* src) {
-#if PYLONG_BITS_IN_DIGIT == 30
+#if PYLONG_BITS_IN_DIGIT == 30 && FQ_DIRECT_DIGITS
     uint64_t lo, hi;
     memcpy(&lo, src, 8);
     memcpy(&hi, src + 8, 8);
@@ -65,7 +101,7 @@ static PyObject* long_from_le16(const unsigned char* src) {
     Py_SET_SIZE(v, n);
     return (PyObject*)v;
 #else
-    return _PyLong_FromByteArray(src, 16, 1, 0);
+    return long_from_le(src, 16);
 #endif
 }
 
@@ -168,7 +204,7 @@ static PyObject* unpack_scalars(PyObject* self, PyObject* args) {
         const Py_ssize_t n = buf.len / 32;
         out = PyList_New(n);
         for (Py_ssize_t i = 0; out && i < n; i++) {
-            PyObject* v = _PyLong_FromByteArray((const unsigned char*)buf.buf + 32 * i, 32, 1, 0);
+            PyObject* v = long_from_le((const unsigned char*)buf.buf + 32 * i, 32);
             if (!v) { Py_CLEAR(out); break; }
             PyList_SET_ITEM(out, i, v);
         }

@@ -134,14 +134,16 @@ def test_many_threads_many_calls():
 def test_a_waiter_that_leaves_by_an_exception_does_not_block_later_callers(monkeypatch):
     """a waiter interrupted inside event.wait() (KeyboardInterrupt in the main thread) used to stay in the queue; picked
     as the next leader later, nobody ran its batch and every following call blocked.  Both cases: interrupted while still queued
-    behind a running batch, and interrupted after having been promoted to lead the next one."""
+    behind a running batch, and interrupted after having been promoted to lead the next one -- and interrupted in the
+    WINDOW between the leader choosing it as heir under the lock and setting its event after releasing the lock."""
     import fourq_amd.combine as combine
 
     class Interrupted(BaseException):
         pass
 
-    for when in ("queued", "promoted"):
+    for when in ("queued", "promoted", "window"):
         gate, first_in, waiting = threading.Event(), threading.Event(), threading.Event()
+        chosen, abandoned = threading.Event(), threading.Event()
 
         class Slot(combine._Slot):
             def __init__(self, args):
@@ -153,8 +155,18 @@ def test_a_waiter_that_leaves_by_an_exception_does_not_block_later_callers(monke
                         waiting.set()
                         if when == "promoted":
                             real_wait(30)                 # woken as the next leader ... and interrupted right then
+                        if when == "window":
+                            assert chosen.wait(30)        # the leader has picked this slot and is about to set its event
                         raise Interrupted()
                     self.event.wait = wait
+                    if when == "window":
+                        real_set = self.event.set
+
+                        def set_():                       # the leader, past its lock: hold it here until the victim has left
+                            chosen.set()
+                            assert abandoned.wait(30)
+                            real_set()
+                        self.event.set = set_
 
         monkeypatch.setattr(combine, "_Slot", Slot)
         sizes = []
@@ -177,6 +189,7 @@ def test_a_waiter_that_leaves_by_an_exception_does_not_block_later_callers(monke
                 cb("victim")
             except Interrupted:
                 out["victim"] = "interrupted"
+            abandoned.set()
         tv = threading.Thread(target=victim)
         tv.start()
         assert waiting.wait(30)

@@ -63,6 +63,8 @@ def test_default_line_has_the_contract_keys():
     assert v4["algorithmic_frac_of_the_algorithm_run"] < v4["algorithmic_frac"]
     lib = line["config"]["library"]
     assert lib["version"] == 400 and len(lib["build_id"]) == 16
+    from fourq_amd import build
+    assert lib["build_id"] == build.source_id() and lib["built_from_these_sources"] is True         # what was timed is what the sources say
     src = r["traffic_source"]
     assert src["loaded_library_build_id"] == lib["build_id"]
     assert (r["traffic"] is None) == (src.get("profiled_library_build_id") != lib["build_id"])      # a figure only for the build it was measured on

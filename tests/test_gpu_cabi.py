@@ -61,3 +61,15 @@ def test_c_host_program_matches_the_oracle(tmp_path):
     proc = subprocess.run([exe, str(path)], capture_output=True, text=True, env=env)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert "bit-exact through the C ABI" in proc.stdout
+
+
+def test_engine_on_the_gpu_box_runs_the_build_of_these_sources():
+    """The snapshot that travels to the GPU box carries the .so built in the container; a header edited without a rebuild would be
+    tested and timed silently.  The id compiled into the library is a hash of the sources: compare them."""
+    from fourq_amd import Engine, _lib, build
+    e = Engine(0)
+    try:
+        assert e.build_id == build.source_id()
+        assert _lib.build_matches_sources() is True
+    finally:
+        e.close()

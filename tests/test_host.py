@@ -34,11 +34,18 @@ def test_constants_match_reference(golden):
 
 
 def test_generated_device_constants_are_current():
-    """fourq_amd/csrc/constants.inc must be what tools/gen_constants.py produces from constants.py."""
+    """fourq_amd/csrc/constants.inc must be what tools/gen_constants.py produces from constants.py.  The check writes nothing: the
+    file is a build dependency, and a rewrite -- even of identical text -- would make build.is_stale() true and cost the next
+    build_library() four translation units."""
+    from fourq_amd import build
     path = os.path.join(ROOT, "fourq_amd", "csrc", "constants.inc")
-    before = open(path).read()
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_constants.py")], check=True, capture_output=True)
-    assert open(path).read() == before
+    stamp, stale = os.stat(path).st_mtime_ns, build.is_stale()
+    tool = os.path.join(ROOT, "tools", "gen_constants.py")
+    assert subprocess.run([sys.executable, tool, "--check"], capture_output=True).returncode == 0
+    assert subprocess.run([sys.executable, tool, "--stdout"], check=True, capture_output=True, text=True).stdout == open(path).read()
+    # the rewriting mode leaves an up-to-date file alone too
+    assert "unchanged" in subprocess.run([sys.executable, tool], check=True, capture_output=True, text=True).stdout
+    assert os.stat(path).st_mtime_ns == stamp and build.is_stale() == stale
 
 
 def test_generated_ladder_bodies_are_current():
@@ -173,6 +180,49 @@ def test_abi_exports_every_declared_symbol():
     for key, code in _lib.PRIM.items():
         assert lib.fourq_prim_words(code, ctypes.byref(iw), ctypes.byref(ow)) == 0 and iw.value and ow.value, key
     assert lib.fourq_prim_words(999, ctypes.byref(iw), ctypes.byref(ow)) == _lib.ERR_INVALID
+
+
+def test_loaded_library_is_built_from_these_sources(tmp_path):
+    """nothing tied the loaded .so to the sources at load time.  fourq_build_id() (a hash of the translation units,
+    headers and flags, compiled in) must equal build.source_id() of the tree -- no GPU needed to ask -- and the loader warns when it
+    does not."""
+    import warnings
+    from fourq_amd import _lib, build
+    lib = _lib.load()
+    assert lib.fourq_build_id().decode() == build.source_id(), "libfourq_amd.so is older than fourq_amd/csrc: python -m fourq_amd.build"
+    assert _lib.build_matches_sources(lib) is True
+
+    class Old:                                     # a library that answers with another id makes the loader speak up
+        @staticmethod
+        def fourq_build_id():
+            return b"0123456789abcdef"
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        _lib._warn_if_not_built_from_these_sources(Old)
+    assert len(seen) == 1 and "was not compiled from the sources" in str(seen[0].message)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        _lib._warn_if_not_built_from_these_sources(lib)
+    assert not seen
+
+
+def test_package_version_is_the_abi_version():
+    import fourq_amd
+    from fourq_amd import _lib
+    major, minor, patch = (int(x) for x in fourq_amd.__version__.split("."))
+    assert 10000 * major + 100 * minor + patch == _lib.ABI_VERSION == _lib.load().fourq_version()
+
+
+def test_a_codec_extension_that_does_not_build_does_not_stop_the_library_build(monkeypatch, capsys):
+    """_fastcodec is optional (codec.py has a pure-Python path); build_library() must warn and go on."""
+    from fourq_amd import build
+
+    def broken(force=False, verbose=False):
+        raise RuntimeError("no C compiler for fourq_amd/csrc/fastcodec.c")
+    monkeypatch.setattr(build, "build_fastcodec", broken)
+    monkeypatch.setattr(build, "is_stale", lambda: False)
+    assert build.build_library() == build.LIB_PATH
+    assert "falls back to its pure-Python conversions" in capsys.readouterr().err
 
 
 def test_library_is_gfx950_only_and_links_no_oracle():

@@ -95,3 +95,63 @@ def test_the_shipped_build_was_placed():
         assert r["placed"], unit
         assert r["at_4_mod_8_before"] > 0.3 * r["wide_instructions"]                 # what hipcc leaves behind (39-45 %)
         assert r["at_4_mod_8_after"] < 0.08 * r["wide_instructions"], (unit, r)      # 1-5 %: short runs behind control flow
+
+
+# ---- the register-ownership check of the build (fourq_amd/build.py check_register_ranges) -------------------------------
+def _listing(tmp_path, body, next_free, accum=None, descriptor=True):
+    text = HEAD + "\t.globl _Z1kv\n_Z1kv:\n" + body + "\ts_endpgm\n"
+    if descriptor:
+        text += "\t.amdhsa_kernel _Z1kv\n\t\t.amdhsa_next_free_vgpr %d\n" % next_free
+        if accum is not None:
+            text += "\t\t.amdhsa_accum_offset %d\n" % accum
+        text += "\t.end_amdhsa_kernel\n"
+    path = tmp_path / "k.s"
+    path.write_text(text)
+    return str(path)
+
+
+def test_register_check_passes_a_kernel_that_owns_what_it_names(tmp_path):
+    from fourq_amd import build
+    build.check_register_ranges(_listing(tmp_path, "\tv_add_u32_e32 v255, v0, v1\n", 256, 256))
+    build.check_register_ranges(_listing(tmp_path, "\tv_mad_u64_u32 v[174:175], vcc, v0, v1, v[2:3]\n", 216, 176))      # 176 arch VGPRs + 40 AGPRs
+
+
+def test_register_check_refuses_a_register_past_the_allocation(tmp_path):
+    from fourq_amd import build
+    with pytest.raises(build.RegisterOwnershipError, match="names v255 but owns 128"):
+        build.check_register_ranges(_listing(tmp_path, "\tv_add_u32_e32 v255, v0, v1\n", 128, 128))
+
+
+def test_register_check_counts_arch_vgprs_not_the_unified_total(tmp_path):
+    """On gfx950 next_free_vgpr is VGPRs + AGPRs: a kernel with accum_offset 176 and 80 AGPRs has next_free_vgpr 256, and a body naming
+    v236 would alias its AGPRs while staying below that total."""
+    from fourq_amd import build
+    with pytest.raises(build.RegisterOwnershipError, match="names v237 but owns 176 arch VGPRs"):
+        build.check_register_ranges(_listing(tmp_path, "\tv_mad_u64_u32 v[236:237], vcc, v0, v1, v[2:3]\n", 256, 176))
+
+
+def test_register_check_refuses_a_listing_it_cannot_read(tmp_path):
+    from fourq_amd import build
+    with pytest.raises(build.RegisterOwnershipError, match="no .amdhsa_next_free_vgpr"):
+        build.check_register_ranges(_listing(tmp_path, "\tv_add_u32_e32 v3, v0, v1\n", 0, descriptor=False))
+
+
+def test_the_placement_fallback_does_not_swallow_a_register_finding(monkeypatch, tmp_path):
+    """one() in build_library() catches RuntimeError from the placement detour and rebuilds without it; the register finding is a
+    different exception type, raised by both paths, so it can never end as a 'code placement failed' log line and a shipped kernel."""
+    from fourq_amd import build
+    assert not issubclass(build.RegisterOwnershipError, RuntimeError)
+    calls = []
+
+    def fake_run(cmd, verbose=False):
+        calls.append(cmd)
+        if "-S" in cmd:
+            out = cmd[cmd.index("-o") + 1]
+            with open(out, "w") as fh:
+                fh.write(open(_listing(tmp_path, "\tv_add_u32_e32 v255, v0, v1\n", 128, 128)).read())
+        return ""
+    monkeypatch.setattr(build, "_run", fake_run)
+    for place in (True, False):
+        with pytest.raises(build.RegisterOwnershipError):
+            build.compile_unit("fourq_amd.hip", str(tmp_path / "x.o"), ["-O3"], place=place, placement={})
+    assert not os.path.exists(str(tmp_path / "x.check.s"))
