@@ -655,6 +655,9 @@ class Bench:
             dt = (time.perf_counter() - t0) / reps
             if not np.array_equal(got, want_words):
                 raise SystemExit("PARITY FAILURE: host-array path (%s, %s) differs from the C oracle" % (workload, label))
+            eng.host_timing(True)                               # one more call with the copies timed (not a timed rep: the events are not free)
+            call()
+            eng.host_timing(False)
             st = eng.host_stats()
             r = {"value": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 4), "gbs_h2d": round(st["gbs_h2d"], 2), "gbs_d2h": round(st["gbs_d2h"], 2),
                  "chunks": st["chunks"], "wall_gbs_both_directions": round(n * (bytes_in + bytes_out) / dt / 1e9, 2)}
@@ -715,8 +718,9 @@ class Bench:
                 rec["at_2^20"][label] = {"value": round(big / dt, 1), "ms_per_step": round(dt * 1e3, 3), "chunks": eng.host_stats()["chunks"],
                                          "wall_gbs_both_directions": round(big * nbytes / dt / 1e9, 2)}
         rec["note"] = ("value = units / wall-clock of the synchronous host-array call (H2D, kernels, D2H pipelined over chunks of whole "
-                       "kernel generations); gbs_* = bytes / summed copy durations (HIP events on the copy streams), i.e. the link rate while a "
-                       "copy is running; every output compared with the C oracle")
+                       "kernel generations, fourq_amd/csrc/pipeline_plan.h); gbs_* = bytes / summed copy durations of ONE EXTRA call made under "
+                       "fourq_ctx_set_host_timing (HIP events on the copy streams), i.e. the link rate while a copy is running; every output "
+                       "compared with the C oracle")
         for a in pins:
             eng.host_free(a)
         return rec
@@ -775,6 +779,15 @@ def _pmc_valu_instructions(workload, build_id):
     if not build_id or profiled != build_id:
         return None
     return (data.get("valu_wave_instructions_per_step") or {}).get(workload)
+
+
+def _built_from_sources():
+    """True when the loaded library's compiled-in id equals the hash of the sources beside it (fourq_amd._lib.build_matches_sources)."""
+    try:
+        from fourq_amd import _lib
+        return _lib.build_matches_sources()
+    except Exception:
+        return None
 
 
 # ---- launcher ----------------------------------------------------------------------------------------------------
@@ -885,7 +898,7 @@ def main():
                        "clock_settle_ms": b.settle_ms, "table_selection": "constant-time (every entry read, FOURQ_CT_SELECT=1)" if b.eng.ct_select
                        else "as the reference (default): digit = table address (curve4q.py:232, :440), sign = masked select (curve4q.py:193-206); "
                             "not constant-time in the digit -- see ct_select for the mode that is",
-                       "library": {"version": b.eng.version, "build_id": b.eng.build_id},
+                       "library": {"version": b.eng.version, "build_id": b.eng.build_id, "built_from_these_sources": _built_from_sources()},
                        "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if world > 1 else None},
             "roofline": rec["roofline"], "valu_roofline": rec["valu_roofline"], "parity": parity,

@@ -24,7 +24,7 @@ RESOURCES_PATH = os.path.join(HERE, "kernel_resources.json")
 PLACEMENT_PATH = os.path.join(HERE, "code_placement.json")
 # four translation units: FQ_CHAIN=0 / 1 (kernels.hip.h), and the constant-time-selection builds of both flavours
 SOURCES = ["fourq_amd.hip", "fourq_chain.hip", "fourq_ct_fused.hip", "fourq_ct_chain.hip"]
-HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "pair.hip.h", "ladder_asm.hip.h", "ladder_asm_gfx950.inc", "constants.inc", os.path.join("..", "..", "include", "fourq_amd.h")]
+HEADERS = ["fp127.hip.h", "curve.hip.h", "recode.hip.h", "kernels.hip.h", "pair.hip.h", "ladder_asm.hip.h", "ladder_asm_gfx950.inc", "constants.inc", "pipeline_plan.h", os.path.join("..", "..", "include", "fourq_amd.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Rpass-analysis=kernel-resource-usage"]
 # Code placement (tools/asmgen/place_asm.py, profiles/r04_ladder_step.txt): the device code of every translation unit goes through
 # assembly text, where every 8-byte instruction is put on an 8-byte boundary (an _e32 instruction in front of it re-encoded as _e64),

@@ -35,6 +35,7 @@
 #define FQ_CHAIN 0
 #endif
 #include "kernels.hip.h"
+#include "pipeline_plan.h"
 
 using namespace fq;
 
@@ -345,6 +346,7 @@ const PrimShape* find_prim(int op) {
 }  // namespace
 
 // ====================================================================================== C ABI
+constexpr int PIPE_SLOTS_MAX = 6;
 struct fourq_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -382,11 +384,15 @@ struct fourq_ctx {
     size_t stage_bytes = 0;
     char* work = nullptr;          // intermediates of the protocol-level calls (decoded points, first-half results)
     size_t work_bytes = 0;
-    // host-pointer batches: PIPE_SLOTS device slots (and pinned bounce slots for pageable callers) cycled through
+    // host-pointer batches: pipe_slots device slots (and pinned bounce slots for pageable callers) cycled through
     // H2D copy -> kernels -> D2H copy on three streams
     hipStream_t copy_in = nullptr, copy_out = nullptr;
-    hipEvent_t in_done[3] = {}, kernels_done[3] = {}, out_done[3] = {};
-    std::vector<hipEvent_t> ticks;     // timing events around the copies of the chunks in flight: four per pipeline slot
+    hipEvent_t in_done[PIPE_SLOTS_MAX] = {}, kernels_done[PIPE_SLOTS_MAX] = {}, out_done[PIPE_SLOTS_MAX] = {};
+    std::vector<hipEvent_t> ticks;     // timing events around the copies, four per chunk of the call: recorded only under host_timing
+    int pipe_slots = 0;            // FOURQ_PIPE_SLOTS (test hook): slots in flight, 2..PIPE_SLOTS_MAX; 0 = 4 when the GPU hands slots on, 3 when the host does
+    int pipe_gens = 0;             // FOURQ_PIPE_GENS (test hook): > 0 = that many kernel generations per inner chunk instead of the planned sizes (pipeline_plan.h)
+    bool pipe_host_wait = false;   // FOURQ_PIPE_HOST_WAIT=1 (test hook): the host waits for a slot's last use before refilling it, as rounds 2-4 did
+    bool host_timing = false;      // fourq_ctx_set_host_timing: time the chunk copies with HIP events (h2d_ms / d2h_ms of fourq_host_stats)
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
     char* zero_copy = nullptr;     // 64 KiB of pinned host memory the kernels of a TINY host call read and write directly (no copy engine)
@@ -656,12 +662,19 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
 }
 
 // ---- host-pointer batches ---------------------------------------------------------------------------------
-// The caller's arrays are cut into chunks of whole kernel generations; chunk k uses slot k mod PIPE_SLOTS and goes
+// The caller's arrays are cut into chunks of whole kernel generations; chunk k uses slot k mod pipe_slots and goes
 // H2D copy (stream copy_in) -> kernels (the context's stream) -> D2H copy (stream copy_out), the three stages of
 // consecutive chunks overlapping.  Arrays in pinned host memory (fourq_host_alloc, hipHostMalloc, torch pin_memory)
 // are copied by DMA straight from / to the caller's buffer; pageable arrays go through pinned bounce slots filled
 // and drained by a few host threads (a single memcpy stream would be slower than the link).
-constexpr int PIPE_SLOTS = 3;
+//
+// Round 5.  What a call costs beyond its kernels is (a) the first chunk's copy in and the last chunk's copy out, which
+// nothing can overlap, and (b) whatever keeps the kernel stream waiting between chunks.  So: the FIRST and the LAST chunk are one generation
+// (the smallest unit that fills the chip), the chunks in between `pipe_gens` generations (fewer stream hops per element); a slot is handed
+// on ON THE GPU -- the copy-in stream waits for the event behind the slot's previous copy-out -- so the host enqueues every chunk without
+// ever blocking and the queues never run dry because the host was asleep in hipEventSynchronize; and the four timing events per chunk
+// are recorded only when the caller asked for copy durations (fourq_ctx_set_host_timing).  Pageable callers keep the host-side hand-over:
+// their bounce slots are filled and drained by the host anyway.
 constexpr int PIPE_MAX_ARRAYS = 4;
 struct PipeArray {
     const char* src;     // input array (host) or NULL
@@ -717,11 +730,22 @@ size_t dh_bytes_work_bytes(size_t n) { return 2 * n * 64 + 2 * align256(n); }
 size_t exchange_work_bytes(size_t n) { return 2 * n * 64 + align256(n); }
 size_t mul_affine_work_bytes(size_t n) { return 2 * n * 160 + n * 64 + align256(n); }      // R1 in, R1 out, decoded points, decode status
 
+int ensure_ticks(fourq_ctx* c, size_t count) {
+    while (c->ticks.size() < count) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreate(&e));
+        try { c->ticks.push_back(e); } catch (...) { (void)hipEventDestroy(e); return FOURQ_ERR_NOMEM; }
+    }
+    return FOURQ_OK;
+}
+
 using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev, size_t m)>;
 
-int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, const ChunkLaunch& launch);
-int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, const ChunkLaunch& launch) {
-    const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, launch);
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch);
+// `chunk`: elements of one kernel generation of the route the call takes; `ns_per_elem`: that route's kernel time per element (the
+// KT_* constants below: what sizes the chunks is the ratio of kernel time to copy time, pipeline_plan.h).
+int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch) {
+    const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, ns_per_elem, launch);
     if (rc != FOURQ_OK) {                      // a chunk failed half way: nothing of this call may still be in flight when the caller
         (void)hipStreamSynchronize(c->copy_in);    // gets its buffers (and the context its slots) back
         (void)hipStreamSynchronize(c->stream);
@@ -729,7 +753,7 @@ int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* o
     }
     return rc;
 }
-int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, const ChunkLaunch& launch) {
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch) {
     if (n_in > PIPE_MAX_ARRAYS || n_out > PIPE_MAX_ARRAYS || chunk == 0) return FOURQ_ERR_INVALID;
     if (chunk > n) chunk = n;
     size_t off_in[PIPE_MAX_ARRAYS], off_out[PIPE_MAX_ARRAYS], slot = 0;
@@ -754,7 +778,7 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     }
     // A single chunk (down to the reference-shaped call, a batch of one): copies and kernels in order on the context's own stream.
     // Nothing can overlap, so the three-stream choreography below would only add its cross-stream event hops (50 us) to the call.
-    // Calls of at most 1 MiB skip even the four timing events (a few us of a 0.19 ms call): their copy durations read 0.
+    // The four timing events around the copies are recorded only under fourq_ctx_set_host_timing; otherwise copy durations read 0.
     // Tiny calls (the batch of one above all): the arrays fit 64 KiB of pinned host memory that the kernels read and write in
     // place -- two CPU memcpys of a few hundred bytes instead of three trips through the copy engine (profiles/r03_single_call.txt).
     constexpr size_t ZERO_COPY_BYTES = 64u << 10;
@@ -778,16 +802,11 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
         c->host_stats = st;
         return FOURQ_OK;
     }
-    const int slots = chunks < (size_t)PIPE_SLOTS ? (int)chunks : PIPE_SLOTS;
-    int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
-    if (rc) return rc;
-    while (c->ticks.size() < 4 * (size_t)PIPE_SLOTS) {
-        hipEvent_t e;
-        HIP_TRY(c, hipEventCreate(&e));
-        c->ticks.push_back(e);
-    }
     if (chunks == 1) {
-        const bool timed = slot > (1u << 20);
+        int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot, false);
+        if (rc) return rc;
+        const bool timed = c->host_timing;
+        if (timed && (rc = ensure_ticks(c, 4))) return rc;
         char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[0], c->stream));
         for (int i = 0; i < n_in; i++) {
@@ -815,25 +834,47 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
         c->host_stats = st;
         return FOURQ_OK;
     }
+    // The chunks of this call (pipeline_plan.h): one generation first and last, growing in between as far as the copies' lead allows
+    size_t bytes_in = 0, bytes_out = 0;
+    for (int i = 0; i < n_in; i++) bytes_in += in[i].stride;
+    for (int i = 0; i < n_out; i++) bytes_out += out[i].stride;
+    using fq_plan::Piece;
+    std::vector<Piece> plan;
+    try { plan = fq_plan::plan_pieces(n, chunk, bytes_in, bytes_out, ns_per_elem, c->pipe_gens); } catch (...) { return FOURQ_ERR_NOMEM; }
+    const size_t pieces = plan.size();
+    size_t big = 0;
+    for (const Piece& pc : plan) if (pc.m > big) big = pc.m;
+    if (big != chunk) {                                                 // the slot layout above was made for `chunk` elements: redo it for `big`
+        slot = 0;
+        for (int i = 0; i < n_in; i++) { off_in[i] = slot; slot += align256(big * in[i].stride); }
+        for (int i = 0; i < n_out; i++) { off_out[i] = slot; slot += align256(big * out[i].stride); }
+    }
+    st.chunks = (uint32_t)pieces;
+    // who hands a slot on: the GPU when every array is copied directly, the host when it has bounce slots to fill and drain
+    const bool host_wait = bounce || c->pipe_host_wait;
+    // slots in flight: four with the GPU's hand-over; three with the host's, where a fourth measured WORSE for raw R1 I/O (6.6 ms against
+    // 5.47 at 2^20, profiles/r05_pipeline.txt: measured on two boxes, cause not established)
+    const int want_slots = c->pipe_slots ? c->pipe_slots : (host_wait ? 3 : 4);
+    const int slots = pieces < (size_t)want_slots ? (int)pieces : want_slots;
+    int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
+    if (rc) return rc;
     if (bounce && (rc = grow(c, &c->pipe_pin, &c->pipe_pin_bytes, slot * slots, true))) return rc;
-
+    const bool timed = c->host_timing;
+    if (timed && (rc = ensure_ticks(c, 4 * pieces))) return rc;
     auto drain = [&](size_t k) -> int {          // chunk k has left the device: hand a pageable caller its bytes
         const int b = (int)(k % slots);
         HIP_TRY(c, hipEventSynchronize(c->out_done[b]));
-        float ms = 0;                                // the slot's timing events belong to chunk k until the slot is reused
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * b], c->ticks[4 * b + 1]));
-        st.h2d_ms += ms;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * b + 2], c->ticks[4 * b + 3]));
-        st.d2h_ms += ms;
-        const size_t off = k * chunk, m = n - off < chunk ? n - off : chunk;
         for (int i = 0; i < n_out; i++)
-            if (!pin_out[i]) host_copy(out[i].dst + off * out[i].stride, c->pipe_pin + (size_t)b * slot + off_out[i], m * out[i].stride);
+            if (!pin_out[i]) host_copy(out[i].dst + plan[k].off * out[i].stride, c->pipe_pin + (size_t)b * slot + off_out[i], plan[k].m * out[i].stride);
         return FOURQ_OK;
     };
-    for (size_t k = 0; k < chunks; k++) {
+    for (size_t k = 0; k < pieces; k++) {
         const int b = (int)(k % slots);
-        if (k >= (size_t)slots && (rc = drain(k - slots))) return rc;       // slot b is free again (device and bounce side)
-        const size_t off = k * chunk, m = n - off < chunk ? n - off : chunk;
+        const size_t off = plan[k].off, m = plan[k].m;
+        if (k >= (size_t)slots) {                                       // slot b is free again once chunk k - slots has been copied out of it
+            if (host_wait) { if ((rc = drain(k - slots))) return rc; }
+            else HIP_TRY(c, hipStreamWaitEvent(c->copy_in, c->out_done[b], 0));    // ... which the kernels of chunk k inherit through in_done[b]
+        }
         char* dev = c->pipe_dev + (size_t)b * slot;
         char* pin = bounce ? c->pipe_pin + (size_t)b * slot : nullptr;
         char *din[PIPE_MAX_ARRAYS], *dout[PIPE_MAX_ARRAYS];
@@ -841,37 +882,54 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             din[i] = dev + off_in[i];
             if (!pin_in[i]) host_copy(pin + off_in[i], in[i].src + off * in[i].stride, m * in[i].stride);
         }
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * b], c->copy_in));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k], c->copy_in));
         for (int i = 0; i < n_in; i++) {
             const char* src = pin_in[i] ? in[i].src + off * in[i].stride : pin + off_in[i];
             HIP_TRY(c, hipMemcpyAsync(din[i], src, m * in[i].stride, hipMemcpyHostToDevice, c->copy_in));
             st.h2d_bytes += m * in[i].stride;
         }
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * b + 1], c->copy_in));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 1], c->copy_in));
         HIP_TRY(c, hipEventRecord(c->in_done[b], c->copy_in));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_done[b], 0));
         for (int i = 0; i < n_out; i++) dout[i] = dev + off_out[i];
         if ((rc = launch(din, dout, m))) return rc;
         HIP_TRY(c, hipEventRecord(c->kernels_done[b], c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->copy_out, c->kernels_done[b], 0));
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * b + 2], c->copy_out));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 2], c->copy_out));
         for (int i = 0; i < n_out; i++) {
             char* dst = pin_out[i] ? out[i].dst + off * out[i].stride : pin + off_out[i];
             HIP_TRY(c, hipMemcpyAsync(dst, dout[i], m * out[i].stride, hipMemcpyDeviceToHost, c->copy_out));
             st.d2h_bytes += m * out[i].stride;
         }
-        HIP_TRY(c, hipEventRecord(c->ticks[4 * b + 3], c->copy_out));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 3], c->copy_out));
         HIP_TRY(c, hipEventRecord(c->out_done[b], c->copy_out));
     }
-    for (size_t k = chunks > (size_t)slots ? chunks - slots : 0; k < chunks; k++)
-        if ((rc = drain(k))) return rc;
+    if (host_wait) {
+        for (size_t k = pieces > (size_t)slots ? pieces - slots : 0; k < pieces; k++)
+            if ((rc = drain(k))) return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->copy_out));      // in order behind every chunk's copy out, which is behind its kernels and its copy in
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (timed) {
+        for (size_t k = 0; k < pieces; k++) {
+            float ms = 0;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k], c->ticks[4 * k + 1]));
+            st.h2d_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k + 2], c->ticks[4 * k + 3]));
+            st.d2h_ms += ms;
+        }
+    }
     c->host_stats = st;
     return FOURQ_OK;
 }
 
 // chunk of a host-pointer batch: whole generations of the kernels that will run it
 size_t pipe_chunk(const fourq_ctx* c, bool fused_route) { return fused_route ? c->lanes : c->lanes_w4; }
+// Kernel time per element of each route in nanoseconds, device-resident at 2^20 elements (profiles/r04_perf_probe.txt, tools/perf_probe.py).
+// They only size the chunks of the host-array calls (pipeline_plan.h): a kernel slower than its figure (constant-time mode, a slower box)
+// gets chunks smaller than it could have had, one faster by more than the plan's 15 % margin a short stall on the first chunks.
+constexpr double KT_ENDO_VAR = 4.63, KT_WIN_VAR = 8.18, KT_DH_VAR = 4.90, KT_ENDO_FIXED = 3.58, KT_WIN_FIXED = 7.65, KT_DH_FIXED = 3.65, KT_COMB = 1.09,
+                 KT_LIFT_LOWER = 0.10, KT_CODEC = 0.30, KT_DECODE = 0.25, KT_ENCODE = 0.05;
 int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out, size_t n) {
     if (!c || !scalars || !out || (!points && !table) || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
@@ -881,7 +939,11 @@ int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* po
     // variable-base MUL_endo: chunks of one fused generation overlap the copies better than rounds of the two-kernel route
     // would (16 chunks instead of 4 at 2^20 elements: 6.7 ms against ~7.8)
     const bool fused = points && (algo == ENDO || !takes_split_route(c, algo, false, n));
-    return run_pipeline(c, in, points ? 2 : 1, o, 1, n, pipe_chunk(c, fused), [&](char* const* di, char* const* dout, size_t m) {
+    // fixed base: the LDS ladders hold two waves per SIMD, so HALF of lanes_w4 is one generation of theirs -- the unit that sizes the first
+    // chunk's copy in and the last chunk's copy out (cfg3's call: 160 B out per element, 21 MB instead of 42 behind the last kernel)
+    const size_t unit = points ? pipe_chunk(c, fused) : c->lanes_w4 / 2;
+    const double kt = points ? (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) : (algo == ENDO ? KT_ENDO_FIXED : KT_WIN_FIXED);
+    return run_pipeline(c, in, points ? 2 : 1, o, 1, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
         return mul_dev(c, algo, (const uint64_t*)di[0], points ? (const uint64_t*)di[1] : nullptr, table, (uint64_t*)dout[0], nullptr, m);
     });
 }
@@ -893,7 +955,9 @@ int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points, nullptr, 64 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     const bool fused = !table && !takes_split_route(c, algo, true, n);
-    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, fused), [&](char* const* di, char* const* dout, size_t m) {
+    const size_t unit = table ? c->lanes_w4 / 2 : pipe_chunk(c, fused);
+    const double kt = table ? KT_DH_FIXED : (algo == ENDO ? KT_DH_VAR : KT_WIN_VAR + 0.3);
+    return run_pipeline(c, in, 2, o, 2, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
         return dh_dev(c, algo, (const uint64_t*)di[0], (const uint64_t*)di[1], table, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -917,7 +981,7 @@ extern "C" {
 
 #define FQ_API __attribute__((visibility("default")))
 
-FQ_API int fourq_version(void) { return 400; }    // 0.4.0; fourq_amd/_lib.py checks it at load time
+FQ_API int fourq_version(void) { return 500; }    // 0.5.0; fourq_amd/_lib.py checks it at load time
 #ifndef FQ_BUILD_ID
 #define FQ_BUILD_ID "unknown"
 #endif
@@ -975,7 +1039,7 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         c->stream = c->own_stream;
         if (hipStreamCreateWithFlags(&c->copy_in, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
         if (hipStreamCreateWithFlags(&c->copy_out, hipStreamNonBlocking) != hipSuccess) { rc = FOURQ_ERR_HIP; break; }
-        for (int i = 0; i < PIPE_SLOTS && rc == FOURQ_OK; i++) {
+        for (int i = 0; i < PIPE_SLOTS_MAX && rc == FOURQ_OK; i++) {
             if (hipEventCreateWithFlags(&c->in_done[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->kernels_done[i], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess) rc = FOURQ_ERR_HIP;
@@ -1001,6 +1065,9 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = route_env("FOURQ_SPLIT_ENDO_MIN")) { long v = atol(env); if (v >= 0) c->split_endo_min = (size_t)v; }
         if (const char* env = route_env("FOURQ_HOST_BOUNCE")) c->host_bounce = atoi(env) != 0;
         if (const char* env = route_env("FOURQ_HOST_ZERO_COPY")) c->host_zero_copy = atoi(env) != 0;
+        if (const char* env = route_env("FOURQ_PIPE_SLOTS")) { int v = atoi(env); if (v >= 2 && v <= PIPE_SLOTS_MAX) c->pipe_slots = v; }
+        if (const char* env = route_env("FOURQ_PIPE_GENS")) { int v = atoi(env); if (v >= 0 && v <= 64) c->pipe_gens = v; }
+        if (const char* env = route_env("FOURQ_PIPE_HOST_WAIT")) c->pipe_host_wait = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
         if (const char* env = route_env("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
         c->pair_max = c->lanes / 2;                        // two lanes per element: half a generation fills the chip
@@ -1054,7 +1121,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->zero_copy) (void)hipHostFree(c->zero_copy);
     if (c->shadow_read) (void)hipEventDestroy(c->shadow_read);
     for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
-    for (int i = 0; i < PIPE_SLOTS; i++) {
+    for (int i = 0; i < PIPE_SLOTS_MAX; i++) {
         if (c->in_done[i]) (void)hipEventDestroy(c->in_done[i]);
         if (c->kernels_done[i]) (void)hipEventDestroy(c->kernels_done[i]);
         if (c->out_done[i]) (void)hipEventDestroy(c->out_done[i]);
@@ -1248,7 +1315,7 @@ FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uin
     CtxGuard g(c);
     PipeArray in[3] = { { (const char*)s, nullptr, 32 }, { (const char*)p, nullptr, 160 }, { (const char*)flags, nullptr, 1 } };
     PipeArray out[1] = { { nullptr, (char*)o, 160 } };
-    return run_pipeline(c, in, 3, out, 1, n, c->split_chunk, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 3, out, 1, n, c->split_chunk, (KT_ENDO_VAR + KT_ENDO_FIXED) / 2, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], (const uint8_t*)di[2], table, (uint64_t*)dout[0], m);
     });
 }
@@ -1347,7 +1414,7 @@ FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uin
     comb = nullptr;
     PipeArray in[1] = { { (const char*)scalars, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, KT_COMB, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_comb_mul_batch_dev(c, (const uint64_t*)di[0], comb, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1374,7 +1441,7 @@ FQ_API int fourq_encode_batch(fourq_ctx* c, const uint64_t* affine, uint8_t* out
     CtxGuard g(c);
     PipeArray in[1] = { { (const char*)affine, nullptr, 64 } };
     PipeArray o[1] = { { nullptr, (char*)out32, 32 } };
-    return run_pipeline(c, in, 1, o, 1, n, 4 * c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 1, o, 1, n, 4 * c->lanes_w4, KT_ENCODE, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_encode_batch_dev(c, (const uint64_t*)di[0], (uint8_t*)dout[0], m);
     });
 }
@@ -1384,7 +1451,7 @@ FQ_API int fourq_decode_batch(fourq_ctx* c, const uint8_t* in32, uint64_t* affin
     CtxGuard g(c);
     PipeArray in[1] = { { (const char*)in32, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)affine, 64 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, KT_DECODE, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_decode_batch_dev(c, (const uint8_t*)di[0], (uint64_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1419,7 +1486,9 @@ static int dh_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const 
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)keys32, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out32, 32 }, { nullptr, (char*)status, 1 } };
     const bool fused = !table && !takes_split_route(c, algo, true, n);
-    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, fused), [&](char* const* di, char* const* dout, size_t m) {
+    const size_t unit = table ? c->lanes_w4 / 2 : pipe_chunk(c, fused);
+    const double kt = (table ? KT_DH_FIXED : (algo == ENDO ? KT_DH_VAR : KT_WIN_VAR + 0.3)) + KT_CODEC;
+    return run_pipeline(c, in, 2, o, 2, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
         return dh_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], table, (uint8_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1449,7 +1518,7 @@ static int mul_affine_host(fourq_ctx* c, int algo, const uint64_t* scalars, cons
     CtxGuard g(c);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points_affine, nullptr, 64 } };
     PipeArray o[1] = { { nullptr, (char*)out_affine, 64 } };
-    return run_pipeline(c, in, 2, o, 1, n, pipe_chunk(c, true), [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 1, n, pipe_chunk(c, true), (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) + KT_LIFT_LOWER, [&](char* const* di, char* const* dout, size_t m) {
         return mul_affine_dev(c, algo, (const uint64_t*)di[0], (const uint64_t*)di[1], (uint64_t*)dout[0], m);
     });
 }
@@ -1476,7 +1545,7 @@ static int mul_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const
     CtxGuard g(c);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points32, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out32, 32 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, true), [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, true), (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) + KT_LIFT_LOWER + KT_CODEC, [&](char* const* di, char* const* dout, size_t m) {
         return mul_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], (uint8_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1534,7 +1603,8 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
     memcpy(base_copy, base_affine, sizeof base_copy);         // the caller's buffer is read once, here
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+    // one generation of the fixed-base half (two waves per SIMD) = two of the variable-base half (one wave per SIMD)
+    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, (table392 ? KT_DH_FIXED : KT_DH_VAR) + KT_DH_VAR, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_dh_exchange_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], base_copy, table392, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1562,7 +1632,7 @@ FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const u
     if (int rc = stage_comb(c, comb)) return rc;                            // compared once, not once per chunk
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, KT_COMB + KT_DH_VAR, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_dh_exchange_comb_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], nullptr, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1578,6 +1648,12 @@ FQ_API int fourq_host_free(fourq_ctx* c, void* ptr) {
     if (!c) return FOURQ_ERR_INVALID;
     CtxGuard g(c);
     HIP_TRY(c, hipHostFree(ptr));
+    return FOURQ_OK;
+}
+FQ_API int fourq_ctx_set_host_timing(fourq_ctx* c, int on) {
+    if (!c) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
+    c->host_timing = on != 0;
     return FOURQ_OK;
 }
 FQ_API int fourq_ctx_host_stats(const fourq_ctx* c, fourq_host_stats* out) {

@@ -125,8 +125,13 @@ class Engine:
             self._ck(self._lib.fourq_host_free(self._ctx, ctypes.c_void_p(addr)))
             del self._pinned[addr]
 
+    def host_timing(self, on):
+        """Time the chunk copies of the following host-array calls (fourq_ctx_set_host_timing): `host_stats()` then reports h2d_ms /
+        d2h_ms and the GB/s they imply.  Off by default -- the event records are not free."""
+        self._ck(self._lib.fourq_ctx_set_host_timing(self._ctx, 1 if on else 0))
+
     def host_stats(self):
-        """Transfer statistics of the last host-array call: dict with h2d/d2h milliseconds, bytes and GB/s."""
+        """Transfer statistics of the last host-array call: bytes, chunks, pinned flags; copy milliseconds and GB/s under host_timing(True)."""
         st = HostStats()
         self._ck(self._lib.fourq_ctx_host_stats(self._ctx, ctypes.byref(st)))
         d = {f: getattr(st, f) for f, _ in HostStats._fields_}

@@ -99,7 +99,7 @@ int fourq_ctx_sync(fourq_ctx *ctx);
  * bit-identical in both modes; the price of ON is in DESIGN.md section 10.
  * Environment: FOURQ_CT_SELECT is the ONE variable the library reads as a product option.  The variables that steer batches onto
  * particular kernels (FOURQ_SPLIT_*, FOURQ_PAIR_MAX, FOURQ_QUAD_MAX, FOURQ_MIXED_QUEUE, FOURQ_NORM_K, FOURQ_BLOCKS_PER_CU,
- * FOURQ_HOST_BOUNCE, FOURQ_HOST_ZERO_COPY) are test hooks: they are ignored unless FOURQ_DEBUG_ROUTES=1 is set (tools/README.md).
+ * FOURQ_HOST_BOUNCE, FOURQ_HOST_ZERO_COPY, FOURQ_PIPE_SLOTS, FOURQ_PIPE_GENS, FOURQ_PIPE_HOST_WAIT) are test hooks: they are ignored unless FOURQ_DEBUG_ROUTES=1 is set (tools/README.md).
  * One variable of the HIP RUNTIME matters to the host-pointer calls: they overlap copy-in, kernels and copy-out on three streams,
  * and the runtime shares GPU_MAX_HW_QUEUES hardware queues (default 4) among all streams the process uses -- in a process with two
  * or more other busy streams the three stages take turns and a large call takes up to twice as long.  Set GPU_MAX_HW_QUEUES=8 in
@@ -128,14 +128,19 @@ int fourq_host_alloc(fourq_ctx *ctx, size_t bytes, void **out);
 int fourq_host_free(fourq_ctx *ctx, void *ptr);
 /* transfer statistics of the context's last host-pointer batch call */
 typedef struct fourq_host_stats {
-    double h2d_ms, d2h_ms;          /* summed durations of the chunk copies (HIP events); 0 for a call of at most 1 MiB, which
-                                     * runs in order on the context's stream untimed (at most 64 KiB: the kernels read and
-                                     * write a pinned host buffer in place, there are no device copies at all) */
+    double h2d_ms, d2h_ms;          /* summed durations of the chunk copies (HIP events), measured only while
+                                     * fourq_ctx_set_host_timing(ctx, 1) is in force -- 0 otherwise: the four event records per
+                                     * chunk are not free, so a production call does not make them (also 0 for a call of at
+                                     * most 64 KiB: its kernels read and write a pinned host buffer in place, there are no
+                                     * device copies at all) */
     uint64_t h2d_bytes, d2h_bytes;  /* bytes moved by device copies: 0 for such an in-place call */
     uint32_t chunks;
     int pinned_in, pinned_out;      /* 1: every input / output array was pinned (no bounce copy) */
 } fourq_host_stats;
 int fourq_ctx_host_stats(const fourq_ctx *ctx, fourq_host_stats *out);
+/* Diagnostic: time the chunk copies of the following host-pointer calls (h2d_ms / d2h_ms above).  OFF by default; bytes, chunk
+ * count and the pinned flags are always reported. */
+int fourq_ctx_set_host_timing(fourq_ctx *ctx, int on);
 
 /* Plain device-memory helpers so that a host program without a HIP binding can use the _dev API. */
 int fourq_dev_alloc(fourq_ctx *ctx, size_t bytes, void **out);

@@ -62,7 +62,7 @@ def test_default_line_has_the_contract_keys():
     assert v4["algorithmic_mads_per_unit_of_the_algorithm_run"] < v4["algorithmic_mads_per_unit"]
     assert v4["algorithmic_frac_of_the_algorithm_run"] < v4["algorithmic_frac"]
     lib = line["config"]["library"]
-    assert lib["version"] == 400 and len(lib["build_id"]) == 16
+    assert lib["version"] == 500 and len(lib["build_id"]) == 16
     from fourq_amd import build
     assert lib["build_id"] == build.source_id() and lib["built_from_these_sources"] is True         # what was timed is what the sources say
     src = r["traffic_source"]

@@ -63,6 +63,7 @@ def test_c_host_program_matches_the_oracle(tmp_path):
     assert "bit-exact through the C ABI" in proc.stdout
 
 
+@pytest.mark.gpu
 def test_engine_on_the_gpu_box_runs_the_build_of_these_sources():
     """The snapshot that travels to the GPU box carries the .so built in the container; a header edited without a rebuild would be
     tested and timed silently.  The id compiled into the library is a hash of the sources: compare them."""

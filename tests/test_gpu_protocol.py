@@ -155,18 +155,23 @@ def test_host_pipeline_chunks_and_pinned_memory(eng, pinned):
     te = oc.table(oc.ENDO, codec.pack_point(G1))
     pts = put(eng.mul_endo_fixed(seeded_scalars(72, n), te))
     out_buf = eng.host_empty((n, 20)) if pinned else None
-    got = eng.mul_endo(s, pts, out=out_buf)
-    st = eng.host_stats()
-    assert st["chunks"] == 3 and st["pinned_in"] == int(pinned) and st["pinned_out"] == int(pinned)
-    assert st["h2d_bytes"] == n * 192 and st["d2h_bytes"] == n * 160 and st["h2d_ms"] > 0 and st["d2h_ms"] > 0
-    assert np.array_equal(got, oc.mul(oc.ENDO, np.asarray(s), np.asarray(pts)))
+    want_mul = oc.mul(oc.ENDO, np.asarray(s), np.asarray(pts))
+    for timing in (False, True):                               # copy durations only on request (fourq_ctx_set_host_timing): the events are not free
+        eng.host_timing(timing)
+        got = eng.mul_endo(s, pts, out=out_buf)
+        st = eng.host_stats()
+        assert st["chunks"] == 3 and st["pinned_in"] == int(pinned) and st["pinned_out"] == int(pinned)      # generation, generation, tail
+        assert st["h2d_bytes"] == n * 192 and st["d2h_bytes"] == n * 160
+        assert (st["h2d_ms"] > 0 and st["d2h_ms"] > 0) if timing else (st["h2d_ms"] == 0 and st["d2h_ms"] == 0)
+        assert np.array_equal(got, want_mul)
+    eng.host_timing(False)
     m = lanes + 77                                             # windowed: two chunks of the fused route
     assert np.array_equal(eng.mul_windowed(s[:m], pts[:m]), oc.mul(oc.WINDOWED, np.asarray(s[:m]), np.asarray(pts[:m])))
     tw = oc.table(oc.WINDOWED, codec.pack_point(G1))
-    n4 = 4 * lanes + 9                                         # fixed base: chunks of 4 x lanes
+    n4 = 4 * lanes + 9                                         # fixed base: a generation of the two-waves-per-SIMD ladders is 2 x lanes
     s4 = put(seeded_scalars(73, n4))
     got = eng.mul_windowed_fixed(s4, tw)
-    assert eng.host_stats()["chunks"] == 2
+    assert eng.host_stats()["chunks"] == 3                     # generation, generation, tail
     assert np.array_equal(got, oc.mul(oc.WINDOWED, np.asarray(s4), None, tw))
     g = np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0)
     aff, st0 = oc.dh(oc.ENDO, seeded_scalars(72, n), g)        # affine inputs: DH_endo(k_i, G)
@@ -185,12 +190,60 @@ def test_host_pipeline_chunks_and_pinned_memory(eng, pinned):
             eng.host_free(arr)
 
 
+@pytest.mark.parametrize("slots,gens,host_wait", [(4, 0, 0), (4, 2, 0), (2, 1, 0), (3, 4, 0), (6, 3, 0), (4, 2, 1), (3, 0, 1)])
+def test_host_pipeline_shapes_slots_handed_on_by_the_gpu(slots, gens, host_wait):
+    """Round 5: the chunks of a large host-array call are one generation first and last and as large in between as the copies' lead allows
+    (fourq_amd/csrc/pipeline_plan.h; `gens` > 0 forces [one] [`gens`]* [rest] [one] [tail] instead), cycled through
+    `slots` device slots that the GPU hands on itself (the copy-in stream waits for the event behind the slot's previous copy-out; the host
+    never blocks while it enqueues).  Every shape of that plan -- fewer chunks than slots, slots reused several times, the host-side
+    hand-over of rounds 2-4, pageable arrays through the bounce slots -- must give the C oracle's words: 7 generations + a ragged tail."""
+    import os
+    from fourq_amd import Engine
+    knobs = {"FOURQ_PIPE_SLOTS": str(slots), "FOURQ_PIPE_GENS": str(gens), "FOURQ_PIPE_HOST_WAIT": str(host_wait)}
+    saved = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        e = Engine(0)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        lanes = e.lanes
+        n = 7 * lanes + 555
+        te = oc.table(oc.ENDO, codec.pack_point(G1))
+        s_h = seeded_scalars(171, n)
+        p_h = e.mul_endo_fixed(seeded_scalars(172, n), te)
+        want = oc.mul(oc.ENDO, s_h, p_h)
+        inner = 5                                                  # generations between the first and the last whole one
+        pieces = 1 + (inner + gens - 1) // gens + 1 + 1 if gens else 8         # planned: raw R1 I/O stays at one generation per chunk (+ the tail)
+        s_p, p_p, o_p = e.host_array(s_h), e.host_array(p_h), e.host_empty((n, 20))
+        for rep in range(2):                                       # the second call finds the slots' events already used
+            got = e.mul_endo(s_p, p_p, out=o_p)
+            st = e.host_stats()
+            assert st["chunks"] == pieces and st["pinned_in"] == 1 and st["pinned_out"] == 1
+            assert np.array_equal(got, want), "pinned, call %d" % rep
+            o_p[:] = 0
+        assert np.array_equal(e.mul_endo(s_h, p_h), want), "pageable"
+        assert e.host_stats()["pinned_in"] == 0
+        # a format with several kernels per chunk and two output arrays
+        a_p, oa_p = e.host_array(oc.r1_to_affine(p_h)), e.host_empty((n, 8))      # the same points, affine
+        got = e.mul_affine(s_p, a_p, out=oa_p)
+        assert np.array_equal(got, oc.r1_to_affine(want))
+        for arr in (s_p, p_p, o_p, a_p, oa_p):
+            e.host_free(arr)
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_small_host_call_runs_in_order_on_the_context_stream(eng, pinned):
-    """A call of one chunk runs in order on the context's stream instead of the three-stream pipeline; at most 1 MiB it is not
-    even timed, and at most 64 KiB (the reference-shaped call is a batch of one) the kernels read and write pinned host memory in
-    place: same results, no device copies hence no byte counts (they used to be reported for what are CPU memcpys), copy
-    durations 0; one element more than 1 MiB and the durations are there."""
+    """A call of one chunk runs in order on the context's stream instead of the three-stream pipeline, and at most 64 KiB (the
+    reference-shaped call is a batch of one) the kernels read and write pinned host memory in place: same results, no device copies
+    hence no byte counts (they used to be reported for what are CPU memcpys).  Copy durations are measured on request only
+    (round 5: fourq_ctx_set_host_timing) and never for the in-place calls."""
     put = (lambda x: eng.host_array(x)) if pinned else (lambda x: x)
     te = oc.table(oc.ENDO, codec.pack_point(G1))
     for n in (1, 7, 185, 186, 2977, 2978):                     # 185 x (32 + 160 + 160) B in 256-byte-aligned arrays: the last size the kernels read and write in pinned host memory directly (64 KiB); 2977: just under 1 MiB; 2978: just over
@@ -202,7 +255,14 @@ def test_small_host_call_runs_in_order_on_the_context_stream(eng, pinned):
         in_place = n <= 185
         assert st["chunks"] == 1 and st["pinned_in"] == int(pinned)
         assert (st["h2d_bytes"], st["d2h_bytes"]) == ((0, 0) if in_place else (n * 192, n * 160))
-        assert (st["h2d_ms"] == 0 and st["d2h_ms"] == 0) if n <= 2977 else (st["h2d_ms"] > 0 and st["d2h_ms"] > 0)
+        assert st["h2d_ms"] == 0 and st["d2h_ms"] == 0
+        eng.host_timing(True)
+        try:
+            assert np.array_equal(eng.mul_endo(s, pts), got)
+            st = eng.host_stats()
+            assert (st["h2d_ms"] == 0 and st["d2h_ms"] == 0) if in_place else (st["h2d_ms"] > 0 and st["d2h_ms"] > 0)
+        finally:
+            eng.host_timing(False)
         g = put(np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0))
         out, status = eng.dh_endo(s, g)
         want, ws = oc.dh(oc.ENDO, np.asarray(s), np.asarray(g))

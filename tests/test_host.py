@@ -82,7 +82,8 @@ def test_every_environment_variable_the_library_reads_is_documented():
     header = open(os.path.join(ROOT, "include", "fourq_amd.h")).read()
     readme = open(os.path.join(ROOT, "tools", "README.md")).read()
     hooks = {"FOURQ_BLOCKS_PER_CU", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_PAIR_MAX",
-             "FOURQ_QUAD_MAX", "FOURQ_MIXED_QUEUE", "FOURQ_NORM_K", "FOURQ_HOST_BOUNCE", "FOURQ_HOST_ZERO_COPY"}
+             "FOURQ_QUAD_MAX", "FOURQ_MIXED_QUEUE", "FOURQ_NORM_K", "FOURQ_HOST_BOUNCE", "FOURQ_HOST_ZERO_COPY",
+             "FOURQ_PIPE_SLOTS", "FOURQ_PIPE_GENS", "FOURQ_PIPE_HOST_WAIT"}
     env_like = {v for v in in_lib if not v.startswith(("FOURQ_ERR", "FOURQ_OK", "FOURQ_DH_", "FOURQ_DECODE", "FOURQ_FP", "FOURQ_PT", "FOURQ_MAX", "FOURQ_TABLE", "FOURQ_COMB_", "FOURQ_R"))}
     assert env_like == hooks | {"FOURQ_CT_SELECT", "FOURQ_DEBUG_ROUTES"}, sorted(env_like ^ (hooks | {"FOURQ_CT_SELECT", "FOURQ_DEBUG_ROUTES"}))
     assert "FOURQ_CT_SELECT" in header and "FOURQ_DEBUG_ROUTES" in header
@@ -160,7 +161,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
         n_args = 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
         assert len(_lib.PROTOTYPES[name][1]) == n_args, name
-    assert lib.fourq_version() == _lib.ABI_VERSION == 400
+    assert lib.fourq_version() == _lib.ABI_VERSION == 500
     assert lib.fourq_strerror(-2).decode() == "no usable gfx950 HIP device"
     # enum values used from Python agree with the header
     for key, val in re.findall(r"FOURQ_(\w+)\s*=\s*(\d+)", header):

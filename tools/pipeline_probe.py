@@ -11,7 +11,11 @@ if "--late-env" in sys.argv:                 # after libamdhip64 is loaded, befo
 from bench import seeded_scalars
 from fourq_amd import Engine, codec, constants
 
-lg = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+lg = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
+FORMATS = next((a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--formats=")), ["r1"])     # r1, affine, bytes, fixed (cfg3's call)
+TIMING = "--timing" in sys.argv              # fourq_ctx_set_host_timing: the four event records per chunk that rounds 2-4 always made
+FLOOR = "--floor" in sys.argv                # also time each format device-resident (one _dev call for the whole batch): the kernels' own pace
+REPS = next((int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--reps=")), 3)
 LINK = "--no-link" not in sys.argv
 STREAMS = "--streams" in sys.argv          # only use two torch streams for a trivial kernel each, no copies
 n = 1 << lg
@@ -49,12 +53,60 @@ g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constan
 with Engine(0) as eng:
     te = eng.table_endo(g1)
     s = eng.host_array(seeded_scalars(1, n))
-    pts = eng.host_array(eng.mul_endo_fixed(seeded_scalars(2, n), te))
-    out = eng.host_empty((n, 20))
-    for name, fn in (("R1", lambda: eng.mul_endo(s, pts, out=out)),):
+    eng.host_timing(TIMING)
+    calls, floors = {}, {}
+    def dev(a):
+        a = np.ascontiguousarray(a)
+        return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to("cuda:0")
+    s_d = dev(np.asarray(s)) if FLOOR else None
+    if "r1" in FORMATS:
+        pts = eng.host_array(eng.mul_endo_fixed(seeded_scalars(2, n), te))
+        out = eng.host_empty((n, 20))
+        calls["r1"] = lambda: eng.mul_endo(s, pts, out=out)
+        if FLOOR:
+            p_d, o_d = dev(np.asarray(pts)), torch.empty((n, 20), dtype=torch.int64, device="cuda:0")
+            floors["r1"] = lambda: eng.mul_endo_dev(s_d, p_d, o_d, n)
+    if "fixed" in FORMATS:
+        tw = eng.table_windowed(g1)
+        outf = eng.host_empty((n, 20))
+        calls["fixed"] = lambda: eng.mul_windowed_fixed(s, tw, out=outf)
+        if FLOOR:
+            of_d = torch.empty((n, 20), dtype=torch.int64, device="cuda:0")
+            floors["fixed"] = lambda: eng.mul_windowed_fixed_dev(s_d, tw, of_d, n)
+    if "affine" in FORMATS or "bytes" in FORMATS:
+        g_aff = np.repeat(codec.pack_point((constants.Gx, constants.Gy)).reshape(1, 8), n, axis=0)
+        aff_h, status = eng.dh_endo(seeded_scalars(2, n), g_aff)             # canonical affine N-torsion points
+        assert not status.any()
+        aff = eng.host_array(aff_h)
+        oa = eng.host_empty((n, 8))
+        calls["affine"] = lambda: eng.mul_affine(s, aff, out=oa)
+        if FLOOR:
+            a_d, oa_d = dev(aff_h), torch.empty((n, 8), dtype=torch.int64, device="cuda:0")
+            eng.reserve(n)
+            floors["affine"] = lambda: eng.mul_affine_dev(s_d, a_d, oa_d, n)
+        if "bytes" in FORMATS:
+            enc = eng.host_array(eng.encode(aff_h))
+            oe, ost = eng.host_empty((n, 32), np.uint8), eng.host_empty((n,), np.uint8)
+            calls["bytes"] = lambda: eng.mul_bytes(s, enc, out=oe, status=ost)
+            if FLOOR:
+                e_d, oe_d, st_d = dev(np.asarray(enc)), torch.empty((n, 32), dtype=torch.uint8, device="cuda:0"), torch.empty(n, dtype=torch.uint8, device="cuda:0")
+                floors["bytes"] = lambda: eng.mul_bytes_dev(s_d, e_d, oe_d, st_d, n)
+    for name in FORMATS:
+        fn = calls[name]
         fn()
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
+        times = []
+        for _ in range(REPS):
+            t0 = time.perf_counter(); fn(); times.append(time.perf_counter() - t0)
+        best, med = min(times), sorted(times)[len(times) // 2]
         st = eng.host_stats()
-        print("%-6s n=2^%d: %.3f ms -> %.1f Mmults/s (chunks %d, copies %.1f / %.1f GB/s)" % (name, lg, best * 1e3, n / best / 1e6, st["chunks"], st["gbs_h2d"] or 0, st["gbs_d2h"] or 0), flush=True)
+        floor = ""
+        if name in floors:
+            for _ in range(2):
+                floors[name]()
+            eng.sync()
+            ft = []
+            for _ in range(REPS):
+                t0 = time.perf_counter(); floors[name](); eng.sync(); ft.append(time.perf_counter() - t0)
+            floor = "  device-resident %.3f ms" % (min(ft) * 1e3)
+        print("%-6s n=2^%d: best %.3f ms  median %.3f ms -> %.1f Mmults/s (chunks %d, copies %.1f / %.1f GB/s)%s" % (
+            name, lg, best * 1e3, med * 1e3, n / best / 1e6, st["chunks"], st["gbs_h2d"] or 0, st["gbs_d2h"] or 0, floor), flush=True)
