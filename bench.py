@@ -403,6 +403,7 @@ class Bench:
             elapsed = float(t.item())
         if workload == "cfg4" and (bool(d["status"][0].any()) or bool(d["status"][1].any())):
             raise SystemExit("cfg4: unexpected DH failure status")
+        clock = self.clock_under_load(step, kernel_ms)           # a diagnostic launch AFTER the timed region: nothing of it is in `elapsed`
         total = n * self.world * steps
         ach_gbs = wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = _pmc_traffic(workload, self.eng.build_id)
@@ -416,6 +417,11 @@ class Bench:
                          "kernel": wl["kernel"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n,
                          "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
             "valu_roofline": valu_roofline(wl, n, kernel_ms),
+            # What makes this line comparable across boxes: MI355X devices hold clocks several percent apart under the
+            # same kernel, so the same code gives 2.14 - 2.24 x 10^8/s on different boxes; in cycles they agree.
+            "clock": clock,
+            "cycles_per_unit": None if not clock else round(kernel_ms * 1e-3 * clock["in_kernel_mhz"] * 1e6 / n, 3),
+            "kernel_cycles_per_step": None if not clock else round(kernel_ms * 1e-3 * clock["in_kernel_mhz"] * 1e6, 0),
         }
         # The bound that actually holds (round 4, profiles/r04_ladder_step.txt): with every 8-byte instruction 8-byte aligned a SIMD issues
         # ONE wave64 VALU instruction per ~4 cycles for this instruction mix, multiply-add or not, at one, two or four waves per SIMD.
@@ -429,6 +435,24 @@ class Bench:
             "source": "SQ_INSTS_VALU of the step's kernels, profiles/pmc_traffic.json (same build-id rule as roofline.traffic)",
             "note": "what is left on this path is the instruction count per unit, not the schedule, the occupancy or the memory system"}
         return rec, d
+
+    def clock_under_load(self, step, kernel_ms, window_ms=25.0):
+        """The shader clock while THIS workload runs, from inside a kernel (MI355X_MICROARCH 'DVFS give-back' item 6): the stream gets a
+        backlog of steps three windows long (the _dev calls only enqueue), and while it drains a 16-wave probe on another stream of the
+        context times `window_ms` of the 100 MHz counter in shader cycles (fourq_diag_clock).  The probe's waves sleep; the product
+        kernels carry no stamp.  Runs right after the timed steps, so the governor is in the state the timed steps saw."""
+        if not hasattr(self.eng, "diag_clock"):
+            return None
+        backlog = max(4, int(3.0 * window_ms / max(kernel_ms, 1e-3)) + 1)
+        for _ in range(backlog):
+            step()
+        c = self.eng.diag_clock(int(window_ms * 1000))
+        GPU.synchronize()
+        return {"in_kernel_mhz": round(c["mhz"], 1), "min_mhz": round(c["mhz_min"], 1), "max_mhz": round(c["mhz_max"], 1), "window_ms": window_ms,
+                "steps_queued_behind_the_probe": backlog,
+                "how": "s_memtime / s_memrealtime x 100 MHz over the window, 16 probe waves (two per XCD) on a side stream while the "
+                       "workload's kernels run back to back (fourq_diag_clock); cycles_per_unit = kernel_ms x this clock / batch_per_gpu = "
+                       "shader cycles of the whole chip per unit of work"}
 
     def parity_gate(self, workload, d):
         """Every output of this rank's shard against the C oracle; raises on any difference."""
@@ -885,10 +909,19 @@ def main():
         if do_ct:
             ct[w] = b.ct_select_record(w, WORKLOADS[w]["batch"], max(5, WORKLOADS[w]["steps"] // 5), 2, want_w, r["ms_per_step"])
 
+    ranks_seen = 1
     if world > 1:                                           # every rank passed its own gate, or the job has already died
         ok = torch.tensor([1.0 if parity["ok"] in (True, None) else 0.0], device="cpu" if rehearse else b.dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         parity["all_ranks_ok"] = bool(ok.item() == 1.0)
+        here = torch.tensor([1.0], device="cpu" if rehearse else b.dev)      # counted, not assumed: one from every rank that got this far
+        dist.all_reduce(here, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(here.item()))
+        # No line unless the job is whole: a value summed over fewer ranks than --gpus, or over a rank whose outputs
+        # were not checked against the oracle, is not a measurement of `--gpus N`.
+        if ranks_seen != args.gpus or not parity["all_ranks_ok"]:
+            raise SystemExit("bench.py --gpus %d: %d ranks reported, all_ranks_ok=%s -- no result line is printed for an incomplete job"
+                             % (args.gpus, ranks_seen, parity["all_ranks_ok"]))
     if rank == 0:
         line = {
             "metric": "FourQ scalar-mults/sec (batch, whole node)", "value": rec["value"], "unit": rec["unit"],
@@ -899,9 +932,10 @@ def main():
                        else "as the reference (default): digit = table address (curve4q.py:232, :440), sign = masked select (curve4q.py:193-206); "
                             "not constant-time in the digit -- see ct_select for the mode that is",
                        "library": {"version": b.eng.version, "build_id": b.eng.build_id, "built_from_these_sources": _built_from_sources()},
-                       "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                       "ranks_seen": ranks_seen,
                        "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if world > 1 else None},
             "roofline": rec["roofline"], "valu_roofline": rec["valu_roofline"], "parity": parity,
+            "clock": rec["clock"], "cycles_per_unit": rec["cycles_per_unit"], "kernel_cycles_per_step": rec["kernel_cycles_per_step"],
         }
         if args.workload == "cfg4":
             line["config"]["note"] = "one unit = one exchange = two DH_core evaluations"

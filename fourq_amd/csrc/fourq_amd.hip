@@ -219,6 +219,22 @@ __global__ __launch_bounds__(BLOCK) void lower_r1_kernel(const u64* r1, u64* aff
     for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
 }
 // status of a two-stage exchange: the first failure of either half (the second half already zeroed its output)
+// Diagnostic (fourq_diag_clock): one wave per block stamps the shader-cycle counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime), sleeps until the latter has advanced by `ticks`, and stamps again: shader cycles per 10 ns = the clock the chip holds
+// while whatever ELSE is running runs.  No product kernel carries a stamp.  Every wave leaves: the wait is on a free-running counter and
+// bounded by a spin limit besides.
+__global__ __launch_bounds__(64) void clock_probe_kernel(u64* stamps, u64 ticks) {
+    const u64 c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    u64 r1 = r0;
+    for (u32 spin = 0; spin < (1u << 24) && r1 - r0 < ticks; spin++) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const u64 c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 __global__ __launch_bounds__(BLOCK) void merge_status_kernel(const uint8_t* first, uint8_t* status, u32 n) {
     u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < n && first[i]) status[i] = first[i];
@@ -1654,6 +1670,31 @@ FQ_API int fourq_ctx_set_host_timing(fourq_ctx* c, int on) {
     if (!c) return FOURQ_ERR_INVALID;
     CtxGuard g(c);
     c->host_timing = on != 0;
+    return FOURQ_OK;
+}
+// The shader clock the chip holds right now, from inside a kernel (MI355X_MICROARCH "DVFS give-back" item 6): a probe of FOURQ_DIAG_BLOCKS
+// single-wave blocks on a stream of the context's own (not the one its kernels are enqueued on), each timing `window_us` of the 100 MHz
+// counter in shader cycles.  Call it while the context's stream has work queued for longer than the window (the _dev calls only enqueue)
+// and the answer is the clock under THAT load: what turns a time measured on one box into cycles comparable with another's.
+FQ_API int fourq_diag_clock(fourq_ctx* c, uint32_t window_us, double* mhz_median, double* mhz_min, double* mhz_max) {
+    if (!c || !mhz_median || window_us == 0 || window_us > 1000000) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
+    constexpr int BLOCKS = 16;                          // consecutive workgroups go to consecutive XCDs: two probes on each of the eight
+    u64* dev = nullptr;
+    HIP_TRY(c, hipMalloc(&dev, 2 * BLOCKS * sizeof(u64)));
+    u64 host[2 * BLOCKS];
+    hipError_t e = hipSuccess;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(BLOCKS), dim3(64), 0, c->copy_out, dev, (u64)window_us * 100u);
+    if ((e = hipGetLastError()) == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, c->copy_out);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->copy_out);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(c, e, "fourq_diag_clock");
+    double mhz[BLOCKS];
+    for (int i = 0; i < BLOCKS; i++) mhz[i] = host[2 * i + 1] ? (double)host[2 * i] / ((double)host[2 * i + 1] / 100.0) : 0.0;
+    for (int i = 1; i < BLOCKS; i++) for (int j = i; j > 0 && mhz[j] < mhz[j - 1]; j--) { const double t = mhz[j]; mhz[j] = mhz[j - 1]; mhz[j - 1] = t; }
+    *mhz_median = 0.5 * (mhz[BLOCKS / 2 - 1] + mhz[BLOCKS / 2]);
+    if (mhz_min) *mhz_min = mhz[0];
+    if (mhz_max) *mhz_max = mhz[BLOCKS - 1];
     return FOURQ_OK;
 }
 FQ_API int fourq_ctx_host_stats(const fourq_ctx* c, fourq_host_stats* out) {

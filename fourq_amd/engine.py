@@ -130,6 +130,13 @@ class Engine:
         d2h_ms and the GB/s they imply.  Off by default -- the event records are not free."""
         self._ck(self._lib.fourq_ctx_set_host_timing(self._ctx, 1 if on else 0))
 
+    def diag_clock(self, window_us=20000):
+        """Shader clock in MHz the device holds right now, measured inside a kernel over `window_us` (fourq_diag_clock): dict with median,
+        min, max over the probe's 16 waves.  Call it with work queued on the engine's stream for longer than the window."""
+        med, lo, hi = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._ck(self._lib.fourq_diag_clock(self._ctx, int(window_us), ctypes.byref(med), ctypes.byref(lo), ctypes.byref(hi)))
+        return {"mhz": med.value, "mhz_min": lo.value, "mhz_max": hi.value, "window_us": int(window_us)}
+
     def host_stats(self):
         """Transfer statistics of the last host-array call: bytes, chunks, pinned flags; copy milliseconds and GB/s under host_timing(True)."""
         st = HostStats()

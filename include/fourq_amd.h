@@ -142,6 +142,14 @@ int fourq_ctx_host_stats(const fourq_ctx *ctx, fourq_host_stats *out);
  * count and the pinned flags are always reported. */
 int fourq_ctx_set_host_timing(fourq_ctx *ctx, int on);
 
+/* Diagnostic: the shader clock (MHz) the device holds at this moment, measured from inside a kernel -- a 16-wave probe on a stream of
+ * the context's own times `window_us` (1 .. 1 000 000) of the constant 100 MHz counter (s_memrealtime) in shader cycles (s_memtime);
+ * median, minimum and maximum over the probe's waves (two per XCD).  Called while the context's stream has work queued for longer than
+ * the window (the _dev calls only enqueue) it reports the clock under that load: a time measured on one box times this clock is a cycle
+ * count comparable with another box's (devices differ by several percent in the clock they hold under the same kernel).  Synchronous
+ * for the window; no product kernel carries a stamp.  mhz_min / mhz_max may be NULL. */
+int fourq_diag_clock(fourq_ctx *ctx, uint32_t window_us, double *mhz_median, double *mhz_min, double *mhz_max);
+
 /* Plain device-memory helpers so that a host program without a HIP binding can use the _dev API. */
 int fourq_dev_alloc(fourq_ctx *ctx, size_t bytes, void **out);
 int fourq_dev_free(fourq_ctx *ctx, void *ptr);

@@ -36,6 +36,11 @@ class OracleEngine:
 
     def mul_endo_dev(self, scalars, points, out, n):
         _np(out)[:] = oc.mul(oc.ENDO, _np(scalars), _np(points))
+        if os.environ.get("FOURQ_STANDIN_CORRUPT_RANK") == os.environ.get("RANK"):       # tests: this rank's gate must catch it and stop the job
+            _np(out)[n // 2, 3] ^= 1
+
+    def diag_clock(self, window_us):
+        return {"mhz": 1000.0, "mhz_min": 1000.0, "mhz_max": 1000.0, "window_us": window_us}     # no shader clock on a CPU: a placeholder
 
     def close(self):
         pass

@@ -69,6 +69,65 @@ def test_two_rank_shard_and_gather_gloo(tmp_path, n):
     assert np.array_equal(np.load(out), want)
 
 
+def _gather_worker(rank, world, port, n_total, cols, result_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(n_total, rank, world)
+        rows = torch.arange(lo, hi, dtype=torch.int64).reshape(-1, 1) * 1000003 + torch.arange(cols, dtype=torch.int64).reshape(1, -1)
+        full = gather_rows(rows, n_total, dst=0)
+        if rank == 0:
+            want = torch.arange(n_total, dtype=torch.int64).reshape(-1, 1) * 1000003 + torch.arange(cols, dtype=torch.int64).reshape(1, -1)
+            with open(result_path, "w") as fh:
+                fh.write("ok" if full.shape == want.shape and torch.equal(full, want) else "MISMATCH %s" % (tuple(full.shape),))
+        else:
+            assert full is None
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,extra", [(2, 1), (3, 2)])
+def test_gather_at_config_4s_real_shard_size_with_uneven_shards(tmp_path, world, extra):
+    """config 4's one collective at its real per-rank size -- 2^19 affine results of 64 bytes per rank, 32 MiB --
+    over gloo, with a total that does not divide by the world size (shards differ by a row; every rank pads to the largest).  The same
+    function runs over nccl (RCCL) on the GPUs; what is checked here is its indexing and trimming at full size."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "verdict.txt")
+    mp.spawn(_gather_worker, args=(world, port, world * (1 << 19) + extra, 8, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_bench_prints_no_line_for_a_job_that_is_not_whole(tmp_path):
+    """`bench.py --gpus N` must not print a result line unless N ranks reported and every rank's outputs passed its
+    oracle gate.  Two ranks over gloo (tests/bench_cpu_rank.py); rank 1's engine returns one wrong word: its gate raises, the job dies,
+    and rank 0 prints nothing that looks like a result."""
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = ["--gpus", "2", "--batch", "256", "--steps", "1", "--warmup", "0", "--no-configs", "--no-pcie", "--no-alongside", "--no-ct", "--no-cpu-baseline"]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   FOURQ_STANDIN_CORRUPT_RANK="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_cpu_rank.py")] + argv, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=180))
+        except subprocess.TimeoutExpired:                     # a rank left waiting for its dead peer: that is a failed job too
+            p.kill()
+            outs.append(p.communicate())
+    assert procs[1].returncode != 0 and "PARITY FAILURE" in outs[1][1]
+    assert procs[0].returncode != 0
+    assert not [ln for o in outs for ln in o[0].splitlines() if ln.startswith('{"metric"')]
+
+
 def test_bench_gpus_n_launches_its_own_ranks_before_touching_a_gpu(monkeypatch, capsys):
     """`python bench.py --gpus N` from a bare shell: the parent builds a torch.distributed.run command on 127.0.0.1 with
     a free port, relays the children's return code and never initialises the GPU runtime itself."""

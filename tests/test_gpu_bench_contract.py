@@ -69,6 +69,15 @@ def test_default_line_has_the_contract_keys():
     assert src["loaded_library_build_id"] == lib["build_id"]
     assert (r["traffic"] is None) == (src.get("profiled_library_build_id") != lib["build_id"])      # a figure only for the build it was measured on
     assert "masked select" in line["config"]["table_selection"]
+    # round 5: every workload record carries the in-kernel clock it was measured at and its cost in cycles (comparable across boxes)
+    for name, rec in [("cfg2", line)] + sorted(line["configs"].items()):
+        clk = rec["clock"]
+        cpu = rec["cycles_per_unit"]
+        assert 1200 < clk["min_mhz"] <= clk["in_kernel_mhz"] <= clk["max_mhz"] < 2600, (name, clk)
+        ms = rec["roofline"]["kernel_ms"]
+        n_units = rec["config"]["batch_per_gpu"] if name == "cfg2" else rec["batch_per_gpu"]
+        assert abs(cpu - ms * 1e-3 * clk["in_kernel_mhz"] * 1e6 / n_units) / cpu < 1e-3, name
+    assert 8.0 < line["cycles_per_unit"] < 13.0                   # MUL_endo, variable base: ~ 650 k wave cycles per generation of 65 536 lanes
     sw = line["size_sweep"]                                        # small batches and remainders run two or four lanes per element: the cliff, driver-visible
     assert sw["1"] < 0.6 * sw["65536"] and sw["1024"] < 0.6 * sw["65536"] and sw["16384"] < sw["32768"] < 0.8 * sw["65536"] and sw["t(65792)/t(65536)"] < 1.75
     sb = line["small_batches"]                                     # the other operations at 1 and 1 024 elements, checked against the oracle
