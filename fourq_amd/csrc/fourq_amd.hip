@@ -757,11 +757,14 @@ int ensure_ticks(fourq_ctx* c, size_t count) {
 
 using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev, size_t m)>;
 
-int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch);
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch, size_t chunk_bounce);
 // `chunk`: elements of one kernel generation of the route the call takes; `ns_per_elem`: that route's kernel time per element (the
-// KT_* constants below: what sizes the chunks is the ratio of kernel time to copy time, pipeline_plan.h).
-int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch) {
-    const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, ns_per_elem, launch);
+// KT_* constants below: what sizes the chunks is the ratio of kernel time to copy time, pipeline_plan.h).  `chunk_bounce` (0 = `chunk`):
+// the uniform chunk of a call from PAGEABLE arrays -- its pace is the host's bounce copies, not the link, and rounds 2-4's larger uniform
+// chunks serve it better (cfg3 from pageable arrays: 16.8 ms in four chunks, 18.5 in six; profiles/r05_pipeline.txt).
+int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch,
+                 size_t chunk_bounce = 0) {
+    const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, ns_per_elem, launch, chunk_bounce);
     if (rc != FOURQ_OK) {                      // a chunk failed half way: nothing of this call may still be in flight when the caller
         (void)hipStreamSynchronize(c->copy_in);    // gets its buffers (and the context its slots) back
         (void)hipStreamSynchronize(c->stream);
@@ -769,8 +772,13 @@ int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* o
     }
     return rc;
 }
-int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch) {
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch, size_t chunk_bounce) {
     if (n_in > PIPE_MAX_ARRAYS || n_out > PIPE_MAX_ARRAYS || chunk == 0) return FOURQ_ERR_INVALID;
+    bool any_pageable = false;
+    for (int i = 0; i < n_in; i++) any_pageable |= !is_pinned(in[i].src);
+    for (int i = 0; i < n_out; i++) any_pageable |= !is_pinned(out[i].dst);
+    const bool uniform = any_pageable && c->host_bounce && chunk_bounce > chunk && n > chunk_bounce;
+    if (uniform) chunk = chunk_bounce;
     if (chunk > n) chunk = n;
     size_t off_in[PIPE_MAX_ARRAYS], off_out[PIPE_MAX_ARRAYS], slot = 0;
     bool pin_in[PIPE_MAX_ARRAYS], pin_out[PIPE_MAX_ARRAYS], bounce = false;
@@ -856,7 +864,7 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     for (int i = 0; i < n_out; i++) bytes_out += out[i].stride;
     using fq_plan::Piece;
     std::vector<Piece> plan;
-    try { plan = fq_plan::plan_pieces(n, chunk, bytes_in, bytes_out, ns_per_elem, c->pipe_gens); } catch (...) { return FOURQ_ERR_NOMEM; }
+    try { plan = fq_plan::plan_pieces(n, chunk, bytes_in, bytes_out, ns_per_elem, (bounce && !c->pipe_gens) ? 1 : c->pipe_gens); } catch (...) { return FOURQ_ERR_NOMEM; }
     const size_t pieces = plan.size();
     size_t big = 0;
     for (const Piece& pc : plan) if (pc.m > big) big = pc.m;
@@ -961,7 +969,7 @@ int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* po
     const double kt = points ? (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) : (algo == ENDO ? KT_ENDO_FIXED : KT_WIN_FIXED);
     return run_pipeline(c, in, points ? 2 : 1, o, 1, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
         return mul_dev(c, algo, (const uint64_t*)di[0], points ? (const uint64_t*)di[1] : nullptr, table, (uint64_t*)dout[0], nullptr, m);
-    });
+    }, pipe_chunk(c, fused));
 }
 int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
             uint8_t* status, size_t n) {
@@ -975,7 +983,7 @@ int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
     const double kt = table ? KT_DH_FIXED : (algo == ENDO ? KT_DH_VAR : KT_WIN_VAR + 0.3);
     return run_pipeline(c, in, 2, o, 2, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
         return dh_dev(c, algo, (const uint64_t*)di[0], (const uint64_t*)di[1], table, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
-    });
+    }, pipe_chunk(c, fused));
 }
 
 int table_host(fourq_ctx* c, int algo, const uint64_t* p_r1, uint64_t* table) {
@@ -1331,9 +1339,12 @@ FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uin
     CtxGuard g(c);
     PipeArray in[3] = { { (const char*)s, nullptr, 32 }, { (const char*)p, nullptr, 160 }, { (const char*)flags, nullptr, 1 } };
     PipeArray out[1] = { { nullptr, (char*)o, 160 } };
-    return run_pipeline(c, in, 3, out, 1, n, c->split_chunk, (KT_ENDO_VAR + KT_ENDO_FIXED) / 2, [&](char* const* di, char* const* dout, size_t m) {
+    // one pass of the work-queue kernel's 4 x CUs waves over 64-element items is `lanes` elements: the unit that lets the copies of a
+    // config-5-sized call (2 x lanes) overlap its kernels; raw R1 in and out keeps the chunks at that size (pipeline_plan.h)
+    const size_t unit = c->split_chunk < c->lanes ? c->split_chunk : c->lanes;
+    return run_pipeline(c, in, 3, out, 1, n, unit, KT_ENDO_VAR, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], (const uint8_t*)di[2], table, (uint64_t*)dout[0], m);
-    });
+    }, c->split_chunk);
 }
 
 FQ_API int fourq_dh_endo_batch(fourq_ctx* c, const uint64_t* s, const uint64_t* p, const uint64_t* t, uint64_t* o, uint8_t* st, size_t n) {
@@ -1506,7 +1517,7 @@ static int dh_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const 
     const double kt = (table ? KT_DH_FIXED : (algo == ENDO ? KT_DH_VAR : KT_WIN_VAR + 0.3)) + KT_CODEC;
     return run_pipeline(c, in, 2, o, 2, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
         return dh_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], table, (uint8_t*)dout[0], (uint8_t*)dout[1], m);
-    });
+    }, pipe_chunk(c, fused));
 }
 // ---- MUL_* with affine / encoded I/O: R1toAffine(MUL_<algo>(m, AffineToR1(P))) and encode(.) of it --------------------------
 // 160 (96) bytes per operation across the ABI instead of the raw-R1 form's 352: the host-array calls are bound by the link, not by the
@@ -1622,7 +1633,7 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
     // one generation of the fixed-base half (two waves per SIMD) = two of the variable-base half (one wave per SIMD)
     return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, (table392 ? KT_DH_FIXED : KT_DH_VAR) + KT_DH_VAR, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_dh_exchange_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], base_copy, table392, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
-    });
+    }, c->lanes_w4);
 }
 
 // dh_exchange with the key-generation half through the comb (bench.py's cfg4 step as one call)
@@ -1650,7 +1661,7 @@ FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const u
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, KT_COMB + KT_DH_VAR, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_dh_exchange_comb_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], nullptr, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
-    });
+    }, c->lanes_w4);
 }
 
 // ---- pinned host memory and transfer statistics of the host-pointer calls ---------------------------------------

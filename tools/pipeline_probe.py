@@ -50,7 +50,20 @@ if STREAMS:
 elif LINK:
     link_test()
 g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
-with Engine(0) as eng:
+ON_TORCH_STREAM = "--torch-stream" in sys.argv      # the engine enqueues on a torch side stream, as bench.py's does
+SECOND_CTX = any(a.startswith("--second-ctx") for a in sys.argv)             # a second context on the same stream that has run kernels (bench.py's constant-time engine)
+side = torch.cuda.Stream(dev) if ON_TORCH_STREAM else None
+if side is not None:
+    torch.cuda.set_stream(side)
+other = None
+if SECOND_CTX:
+    other = Engine(0, stream=side.cuda_stream if side is not None else None)
+    t2 = other.table_endo(g1)
+    other.mul_endo_fixed(seeded_scalars(9, 4096), t2)
+    if "--second-ctx-host" in sys.argv:             # ... and that has made a pipelined host-array call of its own (its copy streams have been used)
+        other.mul_endo_fixed(seeded_scalars(9, 4 << 16), t2)
+print("GPU_MAX_HW_QUEUES=%s torch_stream=%s second_ctx=%s" % (os.environ.get("GPU_MAX_HW_QUEUES"), ON_TORCH_STREAM, SECOND_CTX), flush=True)
+with Engine(0, stream=side.cuda_stream if side is not None else None) as eng:
     te = eng.table_endo(g1)
     s = eng.host_array(seeded_scalars(1, n))
     eng.host_timing(TIMING)
