@@ -232,7 +232,8 @@ def compile_unit(src, obj, flags, verbose=False, place=True, placement=None):
     stats = place_asm.place_file(dev_s, placed_s)
     if placement is not None:
         placement[src] = {"placed": True, "wide_instructions": stats["wide_total"], "at_4_mod_8_before": stats["misaligned_before"],
-                          "at_4_mod_8_after": stats["misaligned_after"], "reencoded": stats["promoted"], "nops": stats["nops"]}
+                          "at_4_mod_8_after": stats["misaligned_after"], "reencoded": stats["promoted"], "nops": stats["nops"],
+                          "instructions_compared_with_the_unplaced_object": stats["instructions_compared"]}
     if verbose:
         print("%s: %d of %d 8-byte instructions at 4 mod 8 before placement, %d after" % (
             src, stats["misaligned_before"], stats["wide_total"], stats["misaligned_after"]), file=sys.stderr)

@@ -155,3 +155,71 @@ def test_the_placement_fallback_does_not_swallow_a_register_finding(monkeypatch,
         with pytest.raises(build.RegisterOwnershipError):
             build.compile_unit("fourq_amd.hip", str(tmp_path / "x.o"), ["-O3"], place=place, placement={})
     assert not os.path.exists(str(tmp_path / "x.check.s"))
+
+
+# ---- placed == unplaced, by construction ------------------------------------------------------------------------
+BODY = ("\ts_getpc_b64 s[4:5]\n\ts_add_u32 s4, s4, g@rel32@lo+4\n\ts_addc_u32 s5, s5, g@rel32@hi+12\n"
+        "\tv_add_u32_e32 v1, v2, v3\n\tv_add_co_u32_e32 v1, vcc, v2, v3\n" + MADS +          # 8-byte run at 4 mod 8 behind an _e32: re-encoded
+        "\ts_cbranch_scc1 .LBB0_1\n" + MADS + "\tv_cndmask_b32_e32 v1, v2, v3, vcc\n"                 # ... behind a branch: one s_nop inserted
+        "\t.p2align 3\n.LBB0_1:\n\tv_cmp_lt_u32_e32 vcc, v1, v2\n" + MADS +                          # the assembler pads here, differently in the two objects
+        "\ts_cbranch_vccnz .LBB0_1\n\ts_nop 0\n\ts_endpgm\n")
+
+
+def _objs(tmp_path, plain_text, placed_text):
+    a, b = tmp_path / "a.s", tmp_path / "b.s"
+    a.write_text(plain_text)
+    b.write_text(placed_text)
+    place_asm.assemble(str(a), str(tmp_path / "a.o"))
+    place_asm.assemble(str(b), str(tmp_path / "b.o"))
+    return str(tmp_path / "a.o"), str(tmp_path / "b.o"), plain_text, placed_text
+
+
+def test_placed_object_is_the_plain_one_plus_padding(tmp_path):
+    text = HEAD + func("f", BODY) + CALLEE
+    src, dst = tmp_path / "in.s", tmp_path / "out.s"
+    src.write_text(text)
+    stats = place_asm.place_file(str(src), str(dst))
+    assert stats["promoted"] >= 1 and stats["nops"] >= 1 and stats["instructions_compared"] >= 25        # the pass did both things it can do, and it was checked
+    a, b, ta, tb = _objs(tmp_path, text, dst.read_text())
+    assert place_asm.check_equivalent(a, b, ta, tb) == stats["instructions_compared"]
+    # forward and backward branches over re-encoded / inserted code still name the same instruction: offsets differ, targets do not
+    plain, placed = place_asm.listing(a)["f"], place_asm.listing(b)["f"]
+    assert [i[2] for i in plain if i[1].startswith("s_cbranch")] != [i[2] for i in placed if i[1].startswith("s_cbranch")]
+
+
+@pytest.mark.parametrize("damage", ["swap", "operand", "drop", "branch", "real-nop"])
+def test_a_corrupted_rewrite_is_caught(tmp_path, damage):
+    """What the check exists for: a rewrite that is NOT the input plus padding -- two instructions swapped, an operand changed, an instruction
+    or a compiler-emitted hazard nop dropped, a branch sent elsewhere -- must fail it."""
+    text = HEAD + func("f", BODY) + CALLEE
+    src, dst = tmp_path / "in.s", tmp_path / "out.s"
+    src.write_text(text)
+    place_asm.place_file(str(src), str(dst))
+    lines = dst.read_text().splitlines(keepends=True)
+    first_mad = next(i for i, ln in enumerate(lines) if "v_mad_u64_u32 v[2:3]" in ln)
+    if damage == "swap":
+        lines[first_mad], lines[first_mad + 1] = lines[first_mad + 1], lines[first_mad]
+    elif damage == "operand":
+        lines[first_mad] = lines[first_mad].replace("v0, v1", "v1, v0")
+    elif damage == "drop":
+        del lines[first_mad]
+    elif damage == "branch":
+        k = next(i for i, ln in enumerate(lines) if "s_cbranch_scc1" in ln)
+        lines[k] = "\ts_cbranch_scc1 .Lelsewhere\n"
+        lines.insert(first_mad + 2, ".Lelsewhere:\n")
+    else:
+        k = max(i for i, ln in enumerate(lines) if ln.strip() == "s_nop 0" and "s_endpgm" in lines[i + 1])     # the compiler's own nop in front of s_endpgm
+        del lines[k]
+    a, b, ta, tb = _objs(tmp_path, text, "".join(lines))
+    with pytest.raises(RuntimeError, match="diverge|differs"):
+        place_asm.check_equivalent(a, b, ta, tb)
+
+
+def test_the_shipped_build_compared_every_unit_with_its_unplaced_object():
+    """build_library() runs the comparison on every translation unit (place_file); the numbers it saw are in code_placement.json."""
+    import json
+    from fourq_amd import build
+    rec = json.load(open(build.PLACEMENT_PATH))
+    assert set(rec) == set(build.SOURCES)
+    for unit, r in rec.items():
+        assert r["placed"] is True and r["instructions_compared_with_the_unplaced_object"] > 40000, unit

@@ -173,6 +173,139 @@ def check_pc_relative(obj):
                     raise RuntimeError("%s: s_getpc_b64 followed by %s" % (name, follow))
 
 
+def listing(obj):
+    """{function symbol: [(address, mnemonic, operand text, size)]} and the symbols' start addresses, from llvm-objdump -d."""
+    out = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", obj], capture_output=True, text=True, check=True).stdout
+    funcs, cur = {}, None
+    for ln in out.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        m = re.match(r"^\t(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):((?:\s+[0-9A-F]{8})+)\s*(?:<.*>)?\s*$", ln)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2), 4 * len(m.group(4).split())))
+    return funcs
+
+
+TERMINATORS = ("s_endpgm", "s_setpc_b64", "s_branch", "s_code_end", "s_trap")
+
+
+def _base(mn):
+    return mn[:-4] if mn.endswith(("_e32", "_e64")) else mn
+
+
+def _simm(text, bits):
+    v = int(text, 0)
+    return v - (1 << bits) if v >= 1 << (bits - 1) else v
+
+
+def padding_of(text, funcs):
+    """{function: set of indices into its object instruction list that have NO line in the assembly text}: what the assembler itself put in
+    for a .p2align (s_nop) or behind the code (s_code_end).  Same walk as place_function's."""
+    lines = text.splitlines()
+    pads, i = {}, 0
+    while i < len(lines):
+        m = re.match(r"^([A-Za-z_.$][\w.$]*):", lines[i])
+        if m and m.group(1) in funcs:
+            name, ins = m.group(1), funcs[m.group(1)]
+            j = i + 1
+            while j < len(lines) and not re.match(r"^\.Lfunc_end\d+:", lines[j]):
+                j += 1
+            k, pad = 0, set()
+            for ln in lines[i + 1:j]:
+                if not is_instruction(ln):
+                    continue
+                mn = ln.strip().split()[0]
+                while k < len(ins) and ins[k][1] != mn and ins[k][1] in ("s_nop", "s_code_end"):
+                    pad.add(k)
+                    k += 1
+                if k >= len(ins) or ins[k][1] != mn:
+                    raise RuntimeError("%s: text and object disagree at %r" % (name, ln.strip()))
+                k += 1
+            pad.update(range(k, len(ins)))                   # behind the last line of the function: padding up to the next symbol
+            pads[name] = pad
+            i = j
+        else:
+            i += 1
+    return pads
+
+
+def check_equivalent(obj_plain, obj_placed, text_plain, text_placed):
+    """The placed object must be the plain one plus padding: per function the same instructions in the same order with the same operands,
+    where `the same` allows exactly what the pass does -- an _e32 instruction re-encoded as _e64, an `s_nop 0` inserted -- and what follows
+    from it -- branch offsets and PC-relative literals that differ in value but name the same instruction.  The ASSEMBLER's padding (the
+    nops of a .p2align, the s_code_end behind a function: object instructions that no line of the text stands for) may differ in length.  Anything else -- a changed operand, a missing or reordered
+    instruction, a branch that lands elsewhere -- raises.  Returns the number of instructions compared.  This is the property that makes
+    the text round-trip of all compiler output safe across a toolchain bump: it is checked on every build."""
+    A, B = listing(obj_plain), listing(obj_placed)
+    if set(A) != set(B):
+        raise RuntimeError("placement changed the set of functions: %s" % sorted(set(A) ^ set(B))[:4])
+    pad_a, pad_b = padding_of(text_plain, A), padding_of(text_placed, B)
+    # (function, address) -> index of the matched pair at or after that address.  Addresses are section offsets and hipcc gives every
+    # function a section of its own, so an address alone names nothing; a branch stays inside its function anyway
+    where_a, where_b, pairs_of = {}, {}, {}
+
+    def nop0(ins):
+        return ins[1] == "s_nop" and ins[2].strip() == "0"
+
+    for name in A:
+        a, b = A[name], B[name]
+        ia = ib = 0
+        pairs, pend_a, pend_b = [], [], []
+        while ia < len(a) or ib < len(b):
+            if (ia < len(a) and ib < len(b) and _base(a[ia][1]) == _base(b[ib][1]) and ia not in pad_a.get(name, ()) and ib not in pad_b.get(name, ())):
+                for addr in pend_a:
+                    where_a[(name, addr)] = len(pairs)
+                for addr in pend_b:
+                    where_b[(name, addr)] = len(pairs)
+                pend_a, pend_b = [], []
+                where_a[(name, a[ia][0])] = where_b[(name, b[ib][0])] = len(pairs)
+                pairs.append((a[ia], b[ib]))
+                ia += 1
+                ib += 1
+                continue
+            if ib < len(b) and (ib in pad_b.get(name, ()) or nop0(b[ib])):      # the assembler's padding, or an `s_nop 0` the pass inserted
+                pend_b.append(b[ib][0])
+                ib += 1
+                continue
+            if ia < len(a) and ia in pad_a.get(name, ()):     # the assembler's padding in the plain object (no line of the text stands behind it):
+                pend_a.append(a[ia][0])                       # a compiler-emitted nop HAS a line and is never skipped on this side
+                ia += 1
+                continue
+            raise RuntimeError("%s: instruction streams diverge at plain #%d %r / placed #%d %r" % (
+                name, ia, a[ia][1:3] if ia < len(a) else None, ib, b[ib][1:3] if ib < len(b) else None))
+        for addr in pend_a:
+            where_a[(name, addr)] = len(pairs)
+        for addr in pend_b:
+            where_b[(name, addr)] = len(pairs)
+        pairs_of[name] = pairs
+    compared = 0
+    for name, pairs in pairs_of.items():
+        for k, (x, y) in enumerate(pairs):
+            compared += 1
+            if x[2] == y[2]:
+                continue
+            mn = _base(x[1])
+            try:
+                if mn.startswith(("s_cbranch", "s_branch", "s_call_b64")):
+                    tx = x[0] + 4 + 4 * _simm(x[2].split(",")[-1].strip(), 16)
+                    ty = y[0] + 4 + 4 * _simm(y[2].split(",")[-1].strip(), 16)
+                    if x[2].split(",")[:-1] == y[2].split(",")[:-1] and (name, tx) in where_a and where_a[(name, tx)] == where_b.get((name, ty)):
+                        continue
+                elif mn == "s_add_u32" and k > 0 and pairs[k - 1][0][1] == "s_getpc_b64":
+                    ox, oy = [t.strip() for t in x[2].split(",")], [t.strip() for t in y[2].split(",")]
+                    tx, ty = x[0] + _simm(ox[-1], 32), y[0] + _simm(oy[-1], 32)
+                    # a literal the assembler resolved itself: the target lies in the same section, i.e. (one function per section) in
+                    # this function; a reference to another section is a relocation and reads the same in both objects
+                    if ox[:-1] == oy[:-1] and (name, tx) in where_a and where_a[(name, tx)] == where_b.get((name, ty)):
+                        continue
+            except (ValueError, IndexError):
+                pass
+            raise RuntimeError("%s: instruction #%d differs: plain %r, placed %r" % (name, k, x[1:3], y[1:3]))
+    return compared
+
+
 def place_file(src, dst, report=False):
     stats = {"promoted": 0, "nops": 0, "left": 0, "wide": 0}
     with tempfile.TemporaryDirectory() as tmp:
@@ -189,6 +322,7 @@ def place_file(src, dst, report=False):
         obj2 = os.path.join(tmp, "out.o")
         assemble(dst, obj2)
         check_pc_relative(obj2)
+        stats["instructions_compared"] = check_equivalent(obj, obj2, text, placed)
         after = misaligned(obj2)
     stats["misaligned_before"], stats["misaligned_after"], stats["wide_total"] = before[0], after[0], after[1]
     if report:
