@@ -170,9 +170,14 @@ def test_host_pipeline_chunks_and_pinned_memory(eng, pinned):
     tw = oc.table(oc.WINDOWED, codec.pack_point(G1))
     n4 = 4 * lanes + 9                                         # fixed base: a generation of the two-waves-per-SIMD ladders is 2 x lanes
     s4 = put(seeded_scalars(73, n4))
-    got = eng.mul_windowed_fixed(s4, tw)
-    assert eng.host_stats()["chunks"] == (3 if pinned else 2)  # pinned: generation, generation, tail; pageable: the larger uniform chunks of rounds 2-4 (4 x lanes) + tail
-    assert np.array_equal(got, oc.mul(oc.WINDOWED, np.asarray(s4), None, tw))
+    got = eng.mul_windowed_fixed(s4, tw)                       # the result array is pageable either way: the larger uniform chunks of rounds 2-4
+    assert eng.host_stats()["chunks"] == 2                     # 4 x lanes + tail
+    want4 = oc.mul(oc.WINDOWED, np.asarray(s4), None, tw)
+    assert np.array_equal(got, want4)
+    if pinned:                                                 # every array pinned: generation, generation, tail
+        o4 = eng.host_empty((n4, 20))
+        assert np.array_equal(eng.mul_windowed_fixed(s4, tw, out=o4), want4) and eng.host_stats()["chunks"] == 3
+        eng.host_free(o4)
     g = np.repeat(codec.pack_point(G).reshape(1, 8), n, axis=0)
     aff, st0 = oc.dh(oc.ENDO, seeded_scalars(72, n), g)        # affine inputs: DH_endo(k_i, G)
     assert not st0.any()
