@@ -267,3 +267,15 @@ def test_null_arguments_are_rejected_without_a_device():
     assert lib.fourq_mul_endo_batch(None, None, None, None, 0) == _lib.ERR_INVALID
     assert lib.fourq_dh_endo_batch(None, None, None, None, None, None, 0) == _lib.ERR_INVALID
     assert lib.fourq_prim_batch(None, 0, None, None, 0) == _lib.ERR_INVALID
+
+
+def test_documents_quote_the_committed_bench_line():
+    """DESIGN.md section 6 and README.md carry numbers generated from profiles/r05_bench_driver_args.json (the driver's protocol); the
+    generator's --check mode must find nothing to change, and neither document has a line a reviewer has to scroll sideways for."""
+    tool = os.path.join(ROOT, "tools", "sync_design_numbers.py")
+    proc = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    for doc in ("DESIGN.md", "HISTORY.md"):
+        long = [i + 1 for i, ln in enumerate(open(os.path.join(ROOT, doc), encoding="utf-8").read().split("\n")) if len(ln) > 200]
+        assert not long, "%s: lines %s are longer than 200 characters" % (doc, long[:5])
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) < 48 * 1024       # the current design only; the rest is HISTORY.md

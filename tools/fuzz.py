@@ -30,7 +30,8 @@ def scalars(n):
 
 def pick_n(lanes):
     edges = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 4095, 4096, 4097, lanes // 4 - 1, lanes // 4, lanes // 4 + 1, lanes // 2, lanes // 2 + 1,
-             lanes - 1, lanes, lanes + 1, lanes + 64, lanes + lanes // 4, lanes + lanes // 4 + 1, 2 * lanes - 1, 2 * lanes, 2 * lanes + 1, 4 * lanes + 3]
+             lanes - 1, lanes, lanes + 1, lanes + 64, lanes + lanes // 4, lanes + lanes // 4 + 1, 2 * lanes - 1, 2 * lanes, 2 * lanes + 1, 4 * lanes + 3,
+             5 * lanes, 7 * lanes + 5]                      # round 5: enough generations for the host-array pipeline to reuse its slots
     return rng.choice(edges) if rng.random() < 0.5 else rng.randrange(1, 3 * lanes)
 
 
@@ -58,7 +59,12 @@ while time.time() < t_end:
         knobs["FOURQ_HOST_ZERO_COPY"] = "0"                              # tiny host calls through hipMemcpyAsync instead of pinned memory read and written in place
     if rng.random() < 0.3:
         knobs["FOURQ_QUAD_MAX"] = rng.choice(["0", "64", "1000"])      # the four-lanes-per-element kernels off / for tiny batches and tails only
-    for k in ("FOURQ_PAIR_MAX", "FOURQ_QUAD_MAX", "FOURQ_HOST_ZERO_COPY", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
+    if rng.random() < 0.5:                                             # round 5: the shape of the host-array pipeline
+        knobs["FOURQ_PIPE_SLOTS"] = rng.choice(["2", "3", "4", "6"])
+        knobs["FOURQ_PIPE_GENS"] = rng.choice(["0", "1", "2", "3"])
+        if rng.random() < 0.3:
+            knobs["FOURQ_PIPE_HOST_WAIT"] = "1"
+    for k in ("FOURQ_PIPE_SLOTS", "FOURQ_PIPE_GENS", "FOURQ_PIPE_HOST_WAIT", "FOURQ_PAIR_MAX", "FOURQ_QUAD_MAX", "FOURQ_HOST_ZERO_COPY", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     with Engine(0) as eng:
@@ -81,7 +87,13 @@ while time.time() < t_end:
                 ok = np.array_equal(eng.mul_endo(s, pts), oc.mul(oc.ENDO, s, pts))
             elif what == "pinned":                           # the same from pinned host arrays (DMA in place, no bounce)
                 sp, pp, op_ = eng.host_array(s), eng.host_array(pts), eng.host_empty((n, 20))
-                ok = np.array_equal(eng.mul_windowed(sp, pp, out=op_), oc.mul(oc.WINDOWED, s, pts))
+                which = rng.choice(["win", "endo", "win_fixed"])
+                if which == "win":
+                    ok = np.array_equal(eng.mul_windowed(sp, pp, out=op_), oc.mul(oc.WINDOWED, s, pts))
+                elif which == "endo":
+                    ok = np.array_equal(eng.mul_endo(sp, pp, out=op_), oc.mul(oc.ENDO, s, pts))
+                else:
+                    ok = np.array_equal(eng.mul_windowed_fixed(sp, tw, out=op_), oc.mul(oc.WINDOWED, s, None, tw))
                 for a_ in (sp, pp, op_):
                     eng.host_free(a_)
             elif what in ("dh_bytes", "exchange"):
