@@ -39,6 +39,17 @@ int main(int argc, char **argv) {
     fourq_host_stats st;
     if ((rc = fourq_ctx_host_stats(ctx, &st)) != FOURQ_OK) return fail("fourq_ctx_host_stats", rc, ctx);
     if (memcmp(pin, want, n * 160) != 0 || st.pinned_out != 1 || st.d2h_bytes != n * 160) { fprintf(stderr, "pinned path differs\n"); return 1; }
+    /* round 5: copy durations only on request, and the in-kernel clock probe */
+    if (st.h2d_ms != 0.0 || st.d2h_ms != 0.0) { fprintf(stderr, "copy durations reported although timing was not asked for\n"); return 1; }
+    if ((rc = fourq_ctx_set_host_timing(ctx, 1)) != FOURQ_OK) return fail("fourq_ctx_set_host_timing", rc, ctx);
+    if ((rc = fourq_mul_endo_batch(ctx, scalars, points, (uint64_t *)pin, (size_t)n)) != FOURQ_OK) return fail("fourq_mul_endo_batch (timed)", rc, ctx);
+    if ((rc = fourq_ctx_host_stats(ctx, &st)) != FOURQ_OK) return fail("fourq_ctx_host_stats", rc, ctx);
+    if (memcmp(pin, want, n * 160) != 0 || (st.d2h_bytes && !(st.h2d_ms > 0.0 && st.d2h_ms > 0.0))) { fprintf(stderr, "timed call differs\n"); return 1; }
+    double mhz = 0, lo = 0, hi = 0;
+    if ((rc = fourq_diag_clock(ctx, 2000, &mhz, &lo, &hi)) != FOURQ_OK) return fail("fourq_diag_clock", rc, ctx);
+    if (!(lo > 100.0 && lo <= mhz && mhz <= hi && hi < 3000.0)) { fprintf(stderr, "implausible clock %.0f MHz (%.0f .. %.0f)\n", mhz, lo, hi); return 1; }
+    if (fourq_diag_clock(ctx, 0, &mhz, NULL, NULL) != FOURQ_ERR_INVALID || fourq_diag_clock(NULL, 10, &mhz, NULL, NULL) != FOURQ_ERR_INVALID) {
+        fprintf(stderr, "fourq_diag_clock accepts bad arguments\n"); return 1; }
     fourq_host_free(ctx, pin);
     fourq_ctx_destroy(ctx);
     printf("cabi_check: %llu elements, MUL_endo and DH_endo bit-exact through the C ABI\n", (unsigned long long)n);
