@@ -411,6 +411,7 @@ struct fourq_ctx {
     bool host_timing = false;      // fourq_ctx_set_host_timing: time the chunk copies with HIP events (h2d_ms / d2h_ms of fourq_host_stats)
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
+    u64* diag_stamps = nullptr;    // fourq_diag_clock: 2 x 16 stamps, allocated at its first call
     char* zero_copy = nullptr;     // 64 KiB of pinned host memory the kernels of a TINY host call read and write directly (no copy engine)
     fourq_host_stats host_stats = {};
     bool host_bounce = true;       // FOURQ_HOST_BOUNCE=0: hand pageable arrays to hipMemcpyAsync directly (measurement knob)
@@ -1143,6 +1144,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->pipe_dev) (void)hipFree(c->pipe_dev);
     if (c->pipe_pin) (void)hipHostFree(c->pipe_pin);
     if (c->zero_copy) (void)hipHostFree(c->zero_copy);
+    if (c->diag_stamps) (void)hipFree(c->diag_stamps);
     if (c->shadow_read) (void)hipEventDestroy(c->shadow_read);
     for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
     for (int i = 0; i < PIPE_SLOTS_MAX; i++) {
@@ -1691,15 +1693,12 @@ FQ_API int fourq_diag_clock(fourq_ctx* c, uint32_t window_us, double* mhz_median
     if (!c || !mhz_median || window_us == 0 || window_us > 1000000) return FOURQ_ERR_INVALID;
     CtxGuard g(c);
     constexpr int BLOCKS = 16;                          // consecutive workgroups go to consecutive XCDs: two probes on each of the eight
-    u64* dev = nullptr;
-    HIP_TRY(c, hipMalloc(&dev, 2 * BLOCKS * sizeof(u64)));
+    if (!c->diag_stamps) HIP_TRY(c, hipMalloc(&c->diag_stamps, 2 * BLOCKS * sizeof(u64)));      // kept: hipFree would wait for the whole device
     u64 host[2 * BLOCKS];
-    hipError_t e = hipSuccess;
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(BLOCKS), dim3(64), 0, c->copy_out, dev, (u64)window_us * 100u);
-    if ((e = hipGetLastError()) == hipSuccess) e = hipMemcpyAsync(host, dev, sizeof host, hipMemcpyDeviceToHost, c->copy_out);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->copy_out);
-    (void)hipFree(dev);
-    if (e != hipSuccess) return fail(c, e, "fourq_diag_clock");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(BLOCKS), dim3(64), 0, c->copy_out, c->diag_stamps, (u64)window_us * 100u);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(host, c->diag_stamps, sizeof host, hipMemcpyDeviceToHost, c->copy_out));
+    HIP_TRY(c, hipStreamSynchronize(c->copy_out));
     double mhz[BLOCKS];
     for (int i = 0; i < BLOCKS; i++) mhz[i] = host[2 * i + 1] ? (double)host[2 * i] / ((double)host[2 * i + 1] / 100.0) : 0.0;
     for (int i = 1; i < BLOCKS; i++) for (int j = i; j > 0 && mhz[j] < mhz[j - 1]; j--) { const double t = mhz[j]; mhz[j] = mhz[j - 1]; mhz[j - 1] = t; }

@@ -66,7 +66,9 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
         for k, ctrs in agg.items():
             if k not in kernels:
                 continue
-            kernels[k]["dispatch"] = info[k]
+            kernels[k]["dispatch"] = dict(info[k], note="as rocprofv3's counter_collection.csv prints the dispatch packet (VGPR_Count there is NOT the compiler's "
+                                                        "register count: fourq_amd/kernel_resources.json has that -- e.g. 256 VGPRs + 40 AGPRs for the headline kernel "
+                                                        "where this field says 148)")
             for c, v in ctrs.items():
                 kernels[k]["counters"][c] = {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
     step_traffic, step_valu = 0.0, 0.0
