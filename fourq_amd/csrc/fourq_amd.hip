@@ -205,18 +205,89 @@ __global__ __launch_bounds__(BLOCK) void lift_affine_kernel(const u64* affine, u
     dst[4] = make_uint4(1, 0, 0, 0); dst[5] = make_uint4(0, 0, 0, 0);                   // Z = 1
     dst[6] = x0; dst[7] = x1; dst[8] = y0; dst[9] = y1;                                  // Ta = X, Tb = Y
 }
-__global__ __launch_bounds__(BLOCK) void lower_r1_kernel(const u64* r1, u64* affine, u32 n) {
+// R1toAffine (curve4q.py:103-106) behind a MUL_*, K elements per lane with ONE GFp.inv (Montgomery's trick inside a lane, as normalize_kernel
+// does for DH batches; fields.py:66-106, :193-199): lane t owns elements t, t + T, ..., t + (K-1) T with T = ceil(n / K).  Z != 0 for every
+// point of the curve (the addition law is complete) -- but MUL_* accepts any pair of field elements (curve4q.py never checks), and the
+// all-zero point a failed decode is lifted to DOES come out with Z = 0: an element whose norm is zero contributes a 1 to the lane's product,
+// so it cannot touch its neighbours, and gets (0, 0) itself -- what conj(0) * 0^(p-2) gives the reference (fields.py:193-199).  A lane's
+// slots past the end of the batch redo its first element and store nothing.  K = 1 for chunks within two generations (one wave per SIMD: the chain's latency is the time either
+// way), K = 4 beyond (throughput: 0.29 -> 0.12 ms per 2^20 elements).  ENC: the result leaves as a 32-byte encoding + status byte
+// (curve4q.py:41-47; 16 + decode status where the input did not decode) instead of 64 bytes of affine words.
+template <int K, bool ENC>
+__global__ __launch_bounds__(BLOCK) void lower_kernel(const u64* r1, const uint8_t* st_decode, u64* out, uint8_t* status, u32 n) {
+    const u32 T = (n + K - 1) / K;
+    const u32 t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    Fe2<1> z[K];
+    Fe<1> nz[K], pre[K];
+#pragma clang loop unroll(full)
+    for (int j = 0; j < K; j++) {
+        const u32 id = t + (u32)j * T, at = id < n ? id : t;
+        z[j] = load_fe2(r1 + 20 * (size_t)at + 8);
+    }
+    Fe<1> one;
+    one.l[0] = 1; one.l[1] = one.l[2] = one.l[3] = one.l[4] = 0;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < K; j++) {
+        const Fe<1> norm = fe_carry(fe_add(fe_sqr(z[j].re), fe_sqr(z[j].im)));
+        nz[j] = (K > 1) ? fe_select(fe_is_zero(norm) ? 0u : ~0u, norm, one) : norm;
+        if (j == 0) pre[0] = nz[0]; else pre[j] = fe_mul(pre[j - 1], nz[j]);
+    }
+    Fe<1> inv = fe_inv(pre[K - 1]);
+#pragma clang loop unroll(full)
+    for (int j = K - 1; j >= 0; j--) {
+        const u32 id = t + (u32)j * T, at = id < n ? id : t;
+        const Fe2<1> X = load_fe2(r1 + 20 * (size_t)at), Y = load_fe2(r1 + 20 * (size_t)at + 4);
+        Fe<1> ninv = inv;                                              // 1 / |Z_j|^2
+        if (j > 0) { ninv = fe_mul(inv, pre[j - 1]); inv = fe_mul(inv, nz[j]); }
+        Fe2<1> zi;
+        zi.re = fe_mul(ninv, z[j].re);                                 // conj(Z) / |Z|^2     fields.py:193-199
+        zi.im = fe_mul(ninv, fe_neg(z[j].im));
+        const Fe2<1> ax = fe2_mul(X, zi), ay = fe2_mul(Y, zi);
+        if (id >= n) continue;
+        if constexpr (ENC) {
+            const uint8_t sd = st_decode[id];
+            const uint8_t st = sd ? (uint8_t)(16 + sd) : (uint8_t)0;
+            u64 w[4];
+            point_encode(ax, ay, w);
+            if (st) w[0] = w[1] = w[2] = w[3] = 0;
+            uint4* dst = reinterpret_cast<uint4*>(out + 4 * (size_t)id);
+            dst[0] = make_uint4((u32)w[0], (u32)(w[0] >> 32), (u32)w[1], (u32)(w[1] >> 32));
+            dst[1] = make_uint4((u32)w[2], (u32)(w[2] >> 32), (u32)w[3], (u32)(w[3] >> 32));
+            status[id] = st;
+        } else {
+            u64 o[8];
+            store_fe2(o, ax); store_fe2(o + 4, ay);
+            uint4* dst = reinterpret_cast<uint4*>(out + 8 * (size_t)id);
+#pragma clang loop unroll(full)
+            for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
+        }
+    }
+}
+// The 32-byte I/O flavour of MUL_* as THREE kernels per chunk instead of five (round 5): decode + AffineToR1 in one (the decoded point
+// never exists as an affine row), R1toAffine + encode + status in one.  Same values as decode_kernel -> lift_affine_kernel and
+// lower_r1_kernel -> encode_status_kernel: a point that does not decode is lifted as all-zero coordinates with Z = 1, its product is
+// computed like any other and its output zeroed by the status (lower_kernel<K, true>).
+__global__ __launch_bounds__(BLOCK) void decode_lift_kernel(const u64* in, u64* r1, uint8_t* status, u32 n) {
     u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    R1 q;
-    q.X = load_fe2(r1 + 20 * (size_t)i); q.Y = load_fe2(r1 + 20 * (size_t)i + 4); q.Z = load_fe2(r1 + 20 * (size_t)i + 8);
-    Fe2<1> ax, ay;
-    r1_to_affine(q, ax, ay);
+    u64 w[4];
+    load_scalar(in + 4 * (size_t)i, w);
+    Fe2<1> x, y;
+    const int st = point_decode(w, x, y);
     u64 o[8];
-    store_fe2(o, ax); store_fe2(o + 4, ay);
-    uint4* dst = reinterpret_cast<uint4*>(affine + 8 * (size_t)i);
+    store_fe2_words(o, x); store_fe2_words(o + 4, y);
+    uint4 q[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
+    for (int k = 0; k < 4; k++) {
+        const u64 lo = st ? 0 : o[2 * k], hi = st ? 0 : o[2 * k + 1];
+        q[k] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+    }
+    uint4* dst = reinterpret_cast<uint4*>(r1 + 20 * (size_t)i);
+    dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];                          // X, Y
+    dst[4] = make_uint4(1, 0, 0, 0); dst[5] = make_uint4(0, 0, 0, 0);                   // Z = 1
+    dst[6] = q[0]; dst[7] = q[1]; dst[8] = q[2]; dst[9] = q[3];                          // Ta = X, Tb = Y
+    status[i] = (uint8_t)st;
 }
 // status of a two-stage exchange: the first failure of either half (the second half already zeroed its output)
 // Diagnostic (fourq_diag_clock): one wave per block stamps the shader-cycle counter (s_memtime) and the constant 100 MHz counter
@@ -1524,6 +1595,21 @@ static int dh_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const 
 // ---- MUL_* with affine / encoded I/O: R1toAffine(MUL_<algo>(m, AffineToR1(P))) and encode(.) of it --------------------------
 // 160 (96) bytes per operation across the ABI instead of the raw-R1 form's 352: the host-array calls are bound by the link, not by the
 // kernels ("PCIe-inclusive").  Parity level L1 (canonical affine); the raw-R1 entry points are untouched.
+// R1toAffine (+ encode) behind a MUL_*: one inversion per element while the chunk is at most two generations, one per four beyond
+static int launch_lower(fourq_ctx* c, bool enc, const uint64_t* r1, const uint8_t* st_decode, uint64_t* out, uint8_t* status, size_t n) {
+    const bool batched = n > 2 * c->lanes;
+    const size_t lanes = batched ? (n + 3) / 4 : n;
+    const unsigned grid = (unsigned)((lanes + BLOCK - 1) / BLOCK);
+    if (enc) {
+        if (batched) hipLaunchKernelGGL((lower_kernel<4, true>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
+        else hipLaunchKernelGGL((lower_kernel<1, true>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
+    } else {
+        if (batched) hipLaunchKernelGGL((lower_kernel<4, false>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
+        else hipLaunchKernelGGL((lower_kernel<1, false>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
 static int mul_affine_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points_affine, uint64_t* out_affine, size_t n) {
     if (!c || !scalars || !points_affine || !out_affine || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(points_affine) || !aligned16(out_affine)) return FOURQ_ERR_INVALID;
@@ -1537,9 +1623,7 @@ static int mul_affine_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const
     hipLaunchKernelGGL(lift_affine_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, points_affine, r1_in, (u32)n);
     HIP_TRY(c, hipGetLastError());
     if ((rc = mul_dev(c, algo, scalars, r1_in, nullptr, r1_out, nullptr, n))) return rc;
-    hipLaunchKernelGGL(lower_r1_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, r1_out, out_affine, (u32)n);
-    HIP_TRY(c, hipGetLastError());
-    return FOURQ_OK;
+    return launch_lower(c, false, r1_out, nullptr, out_affine, nullptr, n);
 }
 static int mul_affine_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points_affine, uint64_t* out_affine, size_t n) {
     if (!c || !scalars || !points_affine || !out_affine || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
@@ -1559,14 +1643,14 @@ static int mul_bytes_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const 
     CtxGuard g(c);
     int rc = ensure_work(c, mul_affine_work_bytes(n));
     if (rc) return rc;
-    uint64_t* pts = (uint64_t*)(c->work + 2 * n * 160);        // decoded points, then the affine results (mul_affine_dev owns the first 320 n bytes)
+    uint64_t* r1_in = (uint64_t*)c->work;                       // decoded and lifted points
+    uint64_t* r1_out = (uint64_t*)(c->work + n * 160);
     uint8_t* st_decode = (uint8_t*)(c->work + 2 * n * 160 + n * 64);
-    if ((rc = fourq_decode_batch_dev(c, points32, pts, st_decode, n))) return rc;
-    if ((rc = mul_affine_dev(c, algo, scalars, pts, pts, n))) return rc;             // in place: every element is read before it is written
-    hipLaunchKernelGGL(encode_status_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, pts, st_decode, (const uint8_t*)nullptr,
-                       (u64*)out32, status, (u32)n);
+    const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(decode_lift_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, (const u64*)points32, r1_in, st_decode, (u32)n);
     HIP_TRY(c, hipGetLastError());
-    return FOURQ_OK;
+    if ((rc = mul_dev(c, algo, scalars, r1_in, nullptr, r1_out, nullptr, n))) return rc;
+    return launch_lower(c, true, r1_out, st_decode, (uint64_t*)out32, status, n);
 }
 static int mul_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint8_t* points32, uint8_t* out32, uint8_t* status, size_t n) {
     if (!c || !scalars || !points32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;

@@ -120,3 +120,64 @@ def test_bytes_flavour_whole_batch_consistency(eng):
     eng.mul_bytes_dev(sd, bd, od, std, n)
     eng.sync()
     assert np.array_equal(od.cpu().numpy(), out) and not std.cpu().numpy().any()
+
+
+def test_batched_normaliser_keeps_elements_independent(eng):
+    """Round 5: past two generations R1toAffine behind a MUL_* shares ONE inversion among four elements of a lane (lower_kernel<4>).
+    MUL_* accepts any pair of field elements (the reference never checks), and the all-zero point -- what a failed decode is lifted
+    to, or what a caller may simply pass -- comes out with Z = 0: such an element must get (0, 0), as the reference's conj(0) * 0^(p-2)
+    gives, and must not touch the three elements that share its inversion.  EVERY element against the C oracle, affine and encoded I/O,
+    garbage at the head of a group, inside one, in all four slots of one lane, and at the ragged end.  The device-resident calls hand the
+    whole batch to one launch (four elements per lane); the host-array calls cut it into chunks of one generation (one element per lane)."""
+    import torch
+    dev = torch.device("cuda", 0)
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a)
+        return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev)
+    lanes = eng.lanes
+    n = 3 * lanes + 41
+    T = (n + 3) // 4                                            # lane t owns t, t + T, t + 2T, t + 3T
+    rng = random.Random(4410)
+    aff = oc.r1_to_affine(oc.mul(oc.ENDO, seeded_scalars(4407, n), None, oc.table(oc.ENDO, codec.pack_point(G1))))
+    s = seeded_scalars(4408, n)
+    zero_at = [0, T, 5, 5 + T, 5 + 2 * T, 5 + 3 * T, 77 + 2 * T, n - 1, 3 * T - 1] + rng.sample(range(n), 40)
+    junk_at = [9, 9 + T] + rng.sample(range(n), 40)
+    aff = aff.copy()
+    for i in junk_at:                                           # arbitrary field elements: not a point of the curve
+        aff[i] = np.frombuffer(rng.getrandbits(512).to_bytes(64, "little"), dtype="<u8") & np.uint64(0x7FFFFFFFFFFFFFFF)
+    for i in zero_at:
+        aff[i] = 0
+    lifted = np.zeros((n, 20), dtype=np.uint64)
+    lifted[:, 0:8] = aff
+    lifted[:, 8] = 1
+    lifted[:, 12:20] = aff
+    # the oracle reduces words >= p as the device does (fe_unpack / % p1271): keep the junk below p so that both read the same value
+    for kind, okind in (("endo", oc.ENDO), ("windowed", oc.WINDOWED)):
+        want = oc.r1_to_affine(oc.mul(okind, s, lifted))
+        assert not want[zero_at].any()                          # (0, 0), by the oracle too
+        od = torch.empty((n, 8), dtype=torch.int64, device=dev)
+        eng.mul_affine_dev(to_dev(s), to_dev(aff), od, n, kind=kind)
+        eng.sync()
+        for got in (od.cpu().numpy().view(np.uint64), eng.mul_affine(s, aff, kind=kind)):
+            bad = np.flatnonzero((got != want).any(axis=1))
+            assert bad.size == 0, (kind, bad[:8], [int(b) % T for b in bad[:8]])
+    # encoded I/O: undecodable strings in the same positions (a reserved bit), everything else decodable
+    ok_aff = oc.r1_to_affine(oc.mul(oc.ENDO, seeded_scalars(4407, n), None, oc.table(oc.ENDO, codec.pack_point(G1))))
+    keys = oc.encode(ok_aff).copy()
+    for i in zero_at:
+        keys[i, 15] |= 0x80
+    lifted_ok = np.zeros((n, 20), dtype=np.uint64)
+    lifted_ok[:, 0:8] = ok_aff
+    lifted_ok[:, 8] = 1
+    lifted_ok[:, 12:20] = ok_aff
+    want_enc = oc.encode(oc.r1_to_affine(oc.mul(oc.ENDO, s, lifted_ok))).copy()
+    want_st = np.zeros(n, dtype=np.uint8)
+    want_enc[zero_at] = 0
+    want_st[zero_at] = 16 + 1
+    got, st = eng.mul_bytes(s, keys)
+    assert np.array_equal(st, want_st) and np.array_equal(got, want_enc)
+    oe, ost = torch.empty((n, 32), dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+    eng.mul_bytes_dev(to_dev(s), to_dev(keys), oe, ost, n)
+    eng.sync()
+    assert np.array_equal(ost.cpu().numpy(), want_st) and np.array_equal(oe.cpu().numpy(), want_enc)
