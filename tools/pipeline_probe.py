@@ -13,6 +13,7 @@ from fourq_amd import Engine, codec, constants
 
 lg = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 FORMATS = next((a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--formats=")), ["r1"])     # r1, affine, bytes, fixed (cfg3's call)
+PAGEABLE = "--pageable" in sys.argv          # plain numpy arrays in and out (the bounce path) instead of pinned ones
 TIMING = "--timing" in sys.argv              # fourq_ctx_set_host_timing: the four event records per chunk that rounds 2-4 always made
 FLOOR = "--floor" in sys.argv                # also time each format device-resident (one _dev call for the whole batch): the kernels' own pace
 REPS = next((int(a.split("=", 1)[1]) for a in sys.argv if a.startswith("--reps=")), 3)
@@ -64,6 +65,9 @@ if SECOND_CTX:
         other.mul_endo_fixed(seeded_scalars(9, 4 << 16), t2)
 print("GPU_MAX_HW_QUEUES=%s torch_stream=%s second_ctx=%s" % (os.environ.get("GPU_MAX_HW_QUEUES"), ON_TORCH_STREAM, SECOND_CTX), flush=True)
 with Engine(0, stream=side.cuda_stream if side is not None else None) as eng:
+    if PAGEABLE:
+        eng.host_array = lambda a, dtype=None: np.ascontiguousarray(a)
+        eng.host_empty = lambda shape, dtype=np.uint64: np.empty(shape, dtype=dtype)
     te = eng.table_endo(g1)
     s = eng.host_array(seeded_scalars(1, n))
     eng.host_timing(TIMING)
