@@ -832,8 +832,9 @@ using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev,
 int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch, size_t chunk_bounce);
 // `chunk`: elements of one kernel generation of the route the call takes; `ns_per_elem`: that route's kernel time per element (the
 // KT_* constants below: what sizes the chunks is the ratio of kernel time to copy time, pipeline_plan.h).  `chunk_bounce` (0 = `chunk`):
-// the uniform chunk of a call from PAGEABLE arrays -- its pace is the host's bounce copies, not the link, and rounds 2-4's larger uniform
-// chunks serve it better (cfg3 from pageable arrays: 16.8 ms in four chunks, 18.5 in six; profiles/r05_pipeline.txt).
+// the uniform chunk of a call from PAGEABLE arrays -- its pace is the host's bounce copies (and, where the call allocates its result, the
+// page faults of 160 fresh bytes per element), not the link: such calls keep the chunk shape they were measured with in rounds 2-4
+// (cfg3's call, result array reused: 10.3-10.4 ms at 2^20 then and now; profiles/r02_host_api.txt, profiles/r05_pipeline.txt).
 int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch,
                  size_t chunk_bounce = 0) {
     const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, ns_per_elem, launch, chunk_bounce);
@@ -846,9 +847,9 @@ int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* o
 }
 int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch, size_t chunk_bounce) {
     if (n_in > PIPE_MAX_ARRAYS || n_out > PIPE_MAX_ARRAYS || chunk == 0) return FOURQ_ERR_INVALID;
-    bool any_pageable = false;
-    for (int i = 0; i < n_in; i++) any_pageable |= !is_pinned(in[i].src);
-    for (int i = 0; i < n_out; i++) any_pageable |= !is_pinned(out[i].dst);
+    bool is_pin_in[PIPE_MAX_ARRAYS], is_pin_out[PIPE_MAX_ARRAYS], any_pageable = false;
+    for (int i = 0; i < n_in; i++) { is_pin_in[i] = is_pinned(in[i].src); any_pageable |= !is_pin_in[i]; }
+    for (int i = 0; i < n_out; i++) { is_pin_out[i] = is_pinned(out[i].dst); any_pageable |= !is_pin_out[i]; }
     const bool uniform = any_pageable && c->host_bounce && chunk_bounce > chunk && n > chunk_bounce;
     if (uniform) chunk = chunk_bounce;
     if (chunk > n) chunk = n;
@@ -863,12 +864,12 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     st.chunks = (uint32_t)chunks;
     st.pinned_in = st.pinned_out = 1;
     for (int i = 0; i < n_in; i++) {
-        const bool pinned = is_pinned(in[i].src);
+        const bool pinned = is_pin_in[i];
         off_in[i] = slot; slot += align256(chunk * in[i].stride); pin_in[i] = pinned || direct_pageable; bounce |= !pin_in[i];
         st.pinned_in &= pinned ? 1 : 0;
     }
     for (int i = 0; i < n_out; i++) {
-        const bool pinned = is_pinned(out[i].dst);
+        const bool pinned = is_pin_out[i];
         off_out[i] = slot; slot += align256(chunk * out[i].stride); pin_out[i] = pinned || direct_pageable; bounce |= !pin_out[i];
         st.pinned_out &= pinned ? 1 : 0;
     }
@@ -955,8 +956,12 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
     if (rc) return rc;
     if (bounce && (rc = grow(c, &c->pipe_pin, &c->pipe_pin_bytes, slot * slots, true))) return rc;
-    const bool timed = c->host_timing;
-    if (timed && (rc = ensure_ticks(c, 4 * pieces))) return rc;
+    // copy timing (on request): four events per chunk for the first TIMED_MAX chunks; a call of more chunks reports their durations
+    // scaled to the call's bytes (a 2^28-element call has 4 096 chunks: it does not get 16 384 events)
+    constexpr size_t TIMED_MAX = 256;
+    const size_t timed_pieces = c->host_timing ? (pieces < TIMED_MAX ? pieces : TIMED_MAX) : 0;
+    if (timed_pieces && (rc = ensure_ticks(c, 4 * timed_pieces))) return rc;
+    uint64_t timed_h2d = 0, timed_d2h = 0;
     auto drain = [&](size_t k) -> int {          // chunk k has left the device: hand a pageable caller its bytes
         const int b = (int)(k % slots);
         HIP_TRY(c, hipEventSynchronize(c->out_done[b]));
@@ -978,11 +983,13 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             din[i] = dev + off_in[i];
             if (!pin_in[i]) host_copy(pin + off_in[i], in[i].src + off * in[i].stride, m * in[i].stride);
         }
+        const bool timed = k < timed_pieces;
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k], c->copy_in));
         for (int i = 0; i < n_in; i++) {
             const char* src = pin_in[i] ? in[i].src + off * in[i].stride : pin + off_in[i];
             HIP_TRY(c, hipMemcpyAsync(din[i], src, m * in[i].stride, hipMemcpyHostToDevice, c->copy_in));
             st.h2d_bytes += m * in[i].stride;
+            if (timed) timed_h2d += m * in[i].stride;
         }
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 1], c->copy_in));
         HIP_TRY(c, hipEventRecord(c->in_done[b], c->copy_in));
@@ -996,6 +1003,7 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             char* dst = pin_out[i] ? out[i].dst + off * out[i].stride : pin + off_out[i];
             HIP_TRY(c, hipMemcpyAsync(dst, dout[i], m * out[i].stride, hipMemcpyDeviceToHost, c->copy_out));
             st.d2h_bytes += m * out[i].stride;
+            if (timed) timed_d2h += m * out[i].stride;
         }
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 3], c->copy_out));
         HIP_TRY(c, hipEventRecord(c->out_done[b], c->copy_out));
@@ -1006,14 +1014,16 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     }
     HIP_TRY(c, hipStreamSynchronize(c->copy_out));      // in order behind every chunk's copy out, which is behind its kernels and its copy in
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (timed) {
-        for (size_t k = 0; k < pieces; k++) {
+    if (timed_pieces) {
+        for (size_t k = 0; k < timed_pieces; k++) {
             float ms = 0;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k], c->ticks[4 * k + 1]));
             st.h2d_ms += ms;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k + 2], c->ticks[4 * k + 3]));
             st.d2h_ms += ms;
         }
+        if (timed_h2d && timed_h2d < st.h2d_bytes) st.h2d_ms *= (double)st.h2d_bytes / (double)timed_h2d;
+        if (timed_d2h && timed_d2h < st.d2h_bytes) st.d2h_ms *= (double)st.d2h_bytes / (double)timed_d2h;
     }
     c->host_stats = st;
     return FOURQ_OK;
