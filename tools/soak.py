@@ -80,10 +80,30 @@ with Engine(0) as eng:
     sp, pp, op_ = eng.host_array(s), eng.host_array(pts), eng.host_empty((n, 20))
     ref = oc.mul(oc.ENDO, s, pts)
     t0 = time.time(); got = eng.mul_endo(sp, pp, out=op_); t1 = time.time()
+    ok = np.array_equal(got, ref)
+    eng.host_timing(True)                            # the copies' durations are measured on request only (round 5): one more call for them
+    op_[:] = 0
+    got = eng.mul_endo(sp, pp, out=op_)
+    eng.host_timing(False)
     st_ = eng.host_stats()
+    ok = ok and np.array_equal(got, ref)
     print("%-28s n=2^%d  GPU %.3fs (PCIe incl., %d chunks, %.0f / %.0f GB/s)  identical=%s" % ("MUL_endo, pinned arrays", LG, t1 - t0, st_["chunks"],
-          st_["gbs_h2d"], st_["gbs_d2h"], np.array_equal(got, ref)), flush=True)
-    assert np.array_equal(got, ref)
+          st_["gbs_h2d"], st_["gbs_d2h"], ok), flush=True)
+    assert ok
+    # round 5: the affine and the encoded I/O of MUL_* at this size (chunks of several generations: four elements share an inversion)
+    aff_in = oc.r1_to_affine(pts)
+    lifted = np.zeros((n, 20), dtype=np.uint64)
+    lifted[:, 0:8] = aff_in; lifted[:, 8] = 1; lifted[:, 12:20] = aff_in
+    want_aff = oc.r1_to_affine(oc.mul(oc.ENDO, s, lifted))
+    ap, oap = eng.host_array(aff_in), eng.host_empty((n, 8))
+    t0 = time.time(); got = eng.mul_affine(sp, ap, out=oap); t1 = time.time()
+    ok = np.array_equal(got, want_aff)
+    print("%-28s n=2^%d  GPU %.3fs (PCIe incl., %d chunks)  identical=%s" % ("MUL_endo affine I/O, pinned", LG, t1 - t0, eng.host_stats()["chunks"], ok), flush=True)
+    assert ok
+    t0 = time.time(); got, gst = eng.mul_bytes(s, oc.encode(aff_in)); t1 = time.time()
+    ok = not gst.any() and np.array_equal(got, oc.encode(want_aff))
+    print("%-28s n=2^%d  GPU %.3fs (PCIe incl., %d chunks)  identical=%s" % ("MUL_endo 32-byte I/O", LG, t1 - t0, eng.host_stats()["chunks"], ok), flush=True)
+    assert ok
     eng.ct_select = True
     for name, gpu, cpu in (("MUL_endo, constant-time", lambda: eng.mul_endo(sp, pp, out=op_), lambda: ref),
                            ("MUL_windowed fixed, constant-time", lambda: eng.mul_windowed_fixed(s, tw), lambda: oc.mul(oc.WINDOWED, s, None, tw)),
