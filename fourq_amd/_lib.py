@@ -30,7 +30,7 @@ BYTES_DECODE_BASE = 16
 class HostStats(ctypes.Structure):
     """struct fourq_host_stats"""
     _fields_ = [("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("h2d_bytes", c_uint64), ("d2h_bytes", c_uint64),
-                ("chunks", ctypes.c_uint32), ("pinned_in", c_int), ("pinned_out", c_int)]
+                ("chunks", ctypes.c_uint32), ("pinned_in", c_int), ("pinned_out", c_int), ("kernels_ms", ctypes.c_double), ("kernels_span_ms", ctypes.c_double)]
 
 
 u64p = POINTER(c_uint64)

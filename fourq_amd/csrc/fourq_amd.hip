@@ -927,6 +927,8 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             st.h2d_ms = ms;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[2], c->ticks[3]));
             st.d2h_ms = ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[1], c->ticks[2]));
+            st.kernels_ms = st.kernels_span_ms = ms;
         }
         c->host_stats = st;
         return FOURQ_OK;
@@ -956,11 +958,11 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
     if (rc) return rc;
     if (bounce && (rc = grow(c, &c->pipe_pin, &c->pipe_pin_bytes, slot * slots, true))) return rc;
-    // copy timing (on request): four events per chunk for the first TIMED_MAX chunks; a call of more chunks reports their durations
-    // scaled to the call's bytes (a 2^28-element call has 4 096 chunks: it does not get 16 384 events)
-    constexpr size_t TIMED_MAX = 256;
+    // timing (on request): six events per chunk -- around its copy in, its kernels, its copy out -- for the first TIMED_MAX chunks; a call of
+    // more chunks reports their copy durations scaled to the call's bytes (a 2^28-element call has 4 096 chunks: it does not get 24 576 events)
+    constexpr size_t TIMED_MAX = 256, TK = 6;
     const size_t timed_pieces = c->host_timing ? (pieces < TIMED_MAX ? pieces : TIMED_MAX) : 0;
-    if (timed_pieces && (rc = ensure_ticks(c, 4 * timed_pieces))) return rc;
+    if (timed_pieces && (rc = ensure_ticks(c, TK * timed_pieces))) return rc;
     uint64_t timed_h2d = 0, timed_d2h = 0;
     auto drain = [&](size_t k) -> int {          // chunk k has left the device: hand a pageable caller its bytes
         const int b = (int)(k % slots);
@@ -984,28 +986,30 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             if (!pin_in[i]) host_copy(pin + off_in[i], in[i].src + off * in[i].stride, m * in[i].stride);
         }
         const bool timed = k < timed_pieces;
-        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k], c->copy_in));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k], c->copy_in));
         for (int i = 0; i < n_in; i++) {
             const char* src = pin_in[i] ? in[i].src + off * in[i].stride : pin + off_in[i];
             HIP_TRY(c, hipMemcpyAsync(din[i], src, m * in[i].stride, hipMemcpyHostToDevice, c->copy_in));
             st.h2d_bytes += m * in[i].stride;
             if (timed) timed_h2d += m * in[i].stride;
         }
-        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 1], c->copy_in));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 1], c->copy_in));
         HIP_TRY(c, hipEventRecord(c->in_done[b], c->copy_in));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_done[b], 0));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 4], c->stream));      // the kernel stream is past its wait: the chunk's bytes are there
         for (int i = 0; i < n_out; i++) dout[i] = dev + off_out[i];
         if ((rc = launch(din, dout, m))) return rc;
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 5], c->stream));
         HIP_TRY(c, hipEventRecord(c->kernels_done[b], c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->copy_out, c->kernels_done[b], 0));
-        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 2], c->copy_out));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 2], c->copy_out));
         for (int i = 0; i < n_out; i++) {
             char* dst = pin_out[i] ? out[i].dst + off * out[i].stride : pin + off_out[i];
             HIP_TRY(c, hipMemcpyAsync(dst, dout[i], m * out[i].stride, hipMemcpyDeviceToHost, c->copy_out));
             st.d2h_bytes += m * out[i].stride;
             if (timed) timed_d2h += m * out[i].stride;
         }
-        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[4 * k + 3], c->copy_out));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 3], c->copy_out));
         HIP_TRY(c, hipEventRecord(c->out_done[b], c->copy_out));
     }
     if (host_wait) {
@@ -1017,11 +1021,16 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     if (timed_pieces) {
         for (size_t k = 0; k < timed_pieces; k++) {
             float ms = 0;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k], c->ticks[4 * k + 1]));
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[TK * k], c->ticks[TK * k + 1]));
             st.h2d_ms += ms;
-            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[4 * k + 2], c->ticks[4 * k + 3]));
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[TK * k + 2], c->ticks[TK * k + 3]));
             st.d2h_ms += ms;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[TK * k + 4], c->ticks[TK * k + 5]));
+            st.kernels_ms += ms;
         }
+        float span = 0;
+        HIP_TRY(c, hipEventElapsedTime(&span, c->ticks[4], c->ticks[TK * (timed_pieces - 1) + 5]));
+        st.kernels_span_ms = span;
         if (timed_h2d && timed_h2d < st.h2d_bytes) st.h2d_ms *= (double)st.h2d_bytes / (double)timed_h2d;
         if (timed_d2h && timed_d2h < st.d2h_bytes) st.d2h_ms *= (double)st.d2h_bytes / (double)timed_d2h;
     }

@@ -136,6 +136,10 @@ typedef struct fourq_host_stats {
     uint64_t h2d_bytes, d2h_bytes;  /* bytes moved by device copies: 0 for such an in-place call */
     uint32_t chunks;
     int pinned_in, pinned_out;      /* 1: every input / output array was pinned (no bounce copy) */
+    double kernels_ms;              /* under fourq_ctx_set_host_timing: summed over the chunks, from "the kernel stream has the chunk's
+                                     * bytes" to "the chunk's kernels are done" (HIP events on the kernel stream); 0 otherwise */
+    double kernels_span_ms;         /* ... and from the first chunk's start to the last chunk's end: span - sum = the kernel stream's idle
+                                     * time between chunks (waiting for bytes, launch gaps) */
 } fourq_host_stats;
 int fourq_ctx_host_stats(const fourq_ctx *ctx, fourq_host_stats *out);
 /* Diagnostic: time the chunk copies of the following host-pointer calls (h2d_ms / d2h_ms above).  OFF by default; bytes, chunk

@@ -176,7 +176,7 @@ def test_abi_exports_every_declared_symbol():
                  "DECODE_OK", "DECODE_RESERVED_BIT", "DECODE_NOT_ON_CURVE", "DECODE_REF_ATTRIBUTE_ERROR"):
         assert value("FOURQ_" + name) == getattr(_lib, name), name
     import ctypes
-    assert ctypes.sizeof(_lib.HostStats) == 48                     # struct fourq_host_stats: 2 doubles, 2 u64, u32 + 2 ints
+    assert ctypes.sizeof(_lib.HostStats) == 64                     # struct fourq_host_stats: 2 doubles, 2 u64, u32 + 2 ints (+ pad), 2 doubles
     iw, ow = ctypes.c_size_t(), ctypes.c_size_t()
     for key, code in _lib.PRIM.items():
         assert lib.fourq_prim_words(code, ctypes.byref(iw), ctypes.byref(ow)) == 0 and iw.value and ow.value, key

@@ -125,5 +125,6 @@ with Engine(0, stream=side.cuda_stream if side is not None else None) as eng:
             for _ in range(REPS):
                 t0 = time.perf_counter(); floors[name](); eng.sync(); ft.append(time.perf_counter() - t0)
             floor = "  device-resident %.3f ms" % (min(ft) * 1e3)
-        print("%-6s n=2^%d: best %.3f ms  median %.3f ms -> %.1f Mmults/s (chunks %d, copies %.1f / %.1f GB/s)%s" % (
-            name, lg, best * 1e3, med * 1e3, n / best / 1e6, st["chunks"], st["gbs_h2d"] or 0, st["gbs_d2h"] or 0, floor), flush=True)
+        kern = "  kernel stream: busy %.3f ms in a span of %.3f" % (st["kernels_ms"], st["kernels_span_ms"]) if st.get("kernels_ms") else ""
+        print("%-6s n=2^%d: best %.3f ms  median %.3f ms -> %.1f Mmults/s (chunks %d, copies %.1f / %.1f GB/s)%s%s" % (
+            name, lg, best * 1e3, med * 1e3, n / best / 1e6, st["chunks"], st["gbs_h2d"] or 0, st["gbs_d2h"] or 0, kern, floor), flush=True)
