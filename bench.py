@@ -696,7 +696,8 @@ class Bench:
             eng.host_timing(False)
             st = eng.host_stats()
             r = {"value": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 4), "best_ms": round(best * 1e3, 4), "gbs_h2d": round(st["gbs_h2d"], 2), "gbs_d2h": round(st["gbs_d2h"], 2),
-                 "chunks": st["chunks"], "wall_gbs_both_directions": round(n * (bytes_in + bytes_out) / dt / 1e9, 2)}
+                 "chunks": st["chunks"], "wall_gbs_both_directions": round(n * (bytes_in + bytes_out) / dt / 1e9, 2),
+                 "kernel_stream_busy_ms": round(st.get("kernels_ms", 0.0), 4), "kernel_stream_span_ms": round(st.get("kernels_span_ms", 0.0), 4)}
             if label == "pinned":
                 rec.update(r)
             elif label == "pageable":
@@ -748,8 +749,9 @@ class Bench:
         rec["note"] = ("value = units / MEDIAN wall-clock of the synchronous host-array call, timed call by call after the device has been brought "
                        "to its sustained clock by repeating the call for clock_settle_ms, as the device-resident steps are (H2D, kernels, D2H pipelined over chunks of whole "
                        "kernel generations, fourq_amd/csrc/pipeline_plan.h); gbs_* = bytes / summed copy durations of ONE EXTRA call made under "
-                       "fourq_ctx_set_host_timing (HIP events on the copy streams), i.e. the link rate while a copy is running; every output "
-                       "compared with the C oracle")
+                       "fourq_ctx_set_host_timing (HIP events on the copy streams), i.e. the link rate while a copy is running; kernel_stream_* = "
+                       "that call's kernel stream: busy with the chunks' kernels, and from the first chunk's start to the last chunk's end; every "
+                       "output compared with the C oracle")
         for a in pins:
             eng.host_free(a)
         return rec
