@@ -74,3 +74,31 @@ def test_engine_on_the_gpu_box_runs_the_build_of_these_sources():
         assert _lib.build_matches_sources() is True
     finally:
         e.close()
+
+
+@pytest.mark.gpu
+def test_clock_probe_reads_a_plausible_shader_clock_idle_and_under_load():
+    """fourq_diag_clock (round 5): 16 probe waves time a window of the 100 MHz counter in shader cycles.  Idle the chip may sit anywhere
+    between its floor and its peak; with the context's stream kept busy by back-to-back MUL_endo launches it must hold a clock in the
+    band MI355X holds under integer load, and the probe must not disturb the results being computed beside it."""
+    import torch
+    from bench import seeded_scalars
+    from fourq_amd import Engine, codec, constants
+    dev = torch.device("cuda", 0)
+    g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
+    with Engine(0) as e:
+        idle = e.diag_clock(2000)
+        assert 100 < idle["mhz_min"] <= idle["mhz"] <= idle["mhz_max"] < 2600, idle
+        n = e.lanes
+        te = e.table_endo(g1)
+        s_h = seeded_scalars(8101, n)
+        p_h = e.mul_endo_fixed(seeded_scalars(8102, n), te)
+        s, p = (torch.from_numpy(a.view(np.int64)).to(dev) for a in (s_h, p_h))
+        out = torch.empty((n, 20), dtype=torch.int64, device=dev)
+        for _ in range(300):                                    # ~90 ms of work queued: the probe's 20 ms window lies inside it
+            e.mul_endo_dev(s, p, out, n)
+        busy = e.diag_clock(20000)
+        e.sync()
+        assert 1500 < busy["mhz_min"] <= busy["mhz"] <= busy["mhz_max"] < 2600, busy
+        assert busy["mhz_max"] - busy["mhz_min"] < 200, busy     # the sixteen probes (two per XCD) agree
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), oc.mul(oc.ENDO, s_h, p_h))
