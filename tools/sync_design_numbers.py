@@ -34,7 +34,7 @@ def design_block(d):
     for k in ("cfg3", "cfg4", "cfg5"):
         r = d["configs"][k]
         rows.append((names[k], r, r["roofline"], r["valu_roofline"], d.get("ct_select", {}).get(k)))
-    out = ["Build `%s`, `%s`:" % (lib["build_id"], SOURCE), "",
+    out = ["Build `%s`, `%s`. The headline on this round's boxes, same protocol:" % (lib["build_id"], SOURCE), runs_sentence(d) + ".", "",
            "| configuration (per GPU) | units/s | ms / step | in-kernel clock | cycles / unit | `issue` | algorithmic / executed frac | traffic vs algorithmic | constant-time |",
            "|---|---|---|---|---|---|---|---|---|"]
     for name, r, roof, valu, ct in rows:
@@ -78,16 +78,35 @@ def design_block(d):
     return "\n".join(out)
 
 
+def earlier_runs():
+    """The same protocol on other boxes of the pool this round (builds that differ only in host code: the kernels are round 4's)."""
+    runs = []
+    for k in (1, 2, 3, 4):
+        path = os.path.join(ROOT, "profiles", "r05_bench_driver_args_run%d.json" % k)
+        if os.path.exists(path):
+            with open(path) as fh:
+                runs.append(json.load(fh))
+    return runs
+
+
+def runs_sentence(d):
+    runs = earlier_runs() + [d]
+    return "; ".join("%s at %.0f MHz = %.2f cycles per element" % (e8(r["value"]), r["clock"]["in_kernel_mhz"], r["cycles_per_unit"]) for r in runs)
+
+
 def readme_block(d):
     c = d["configs"]
     big = d["pcie_inclusive"]["at_2^20"]
-    return ("Numbers of `python bench.py --steps 20 --warmup 5` — the driver's protocol — on one MI355X (`%s`; boxes of the pool differ by several\n"
-            "percent in the clock they hold, the same build has read 2.14–2.24×10⁸/s, so the line carries the in-kernel clock and cycles per unit):\n"
-            "**%s** variable-base scalar multiplications per second at a batch of 2¹⁶ (device-resident, %.0f MHz, %.2f cycles per element;\n"
+    vals = [r["value"] for r in earlier_runs() + [d]]
+    head = e8(d["value"]) if len(vals) == 1 else "%.2f–%s" % (min(vals) / 1e8, e8(max(vals)))
+    return ("Numbers of `python bench.py --steps 20 --warmup 5` — the driver's protocol — on one MI355X (`%s`). Boxes of the pool hold clocks\n"
+            "several percent apart under the same kernel, so the line carries the in-kernel clock and cycles per unit; this round's runs of the protocol:\n"
+            "%s.\n"
+            "**%s** variable-base scalar multiplications per second at a batch of 2¹⁶ (device-resident;\n"
             "%s/s from pinned host arrays at 2²⁰, PCIe included), %s fixed-base `MUL_windowed`/s, %s Diffie-Hellman exchanges/s,\n"
             "%s/s on the 50/50 fixed / variable mix (one persistent kernel pulling work items off a device-side queue), every output checked\n"
             "bit-exact against the C restatement of the reference in the same run; the pure-Python path does %.1g/s on the same box's %d cores." % (
-                SOURCE, e8(d["value"]), d["clock"]["in_kernel_mhz"], d["cycles_per_unit"], e8(big["r1"]["value"]), e8(c["cfg3"]["value"]), e8(c["cfg4"]["value"]),
+                SOURCE, runs_sentence(d), head, e8(big["r1"]["value"]), e8(c["cfg3"]["value"]), e8(c["cfg4"]["value"]),
                 e8(c["cfg5"]["value"]), d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"]))
 
 
