@@ -41,30 +41,27 @@ VALU_MAD_PEAK_MEASURED = 1024 * 64 / 1.84e-9
 # EXECUTES per unit in radix 2^26 (M = 100, S = 50; DBL = 3M+4S = 500, ADD = 8M = 800; ladder step 1 300 x 64 endo,
 # 4 DBL + ADD = 2 800 x 62 windowed; table_endo 14 300; DH extras 8 600 (6 800 with the shared inversion); comb
 # 6 DBL + 27 mixed ADD (7M) = 21 900 + its share of an inversion): DESIGN.md section 5.
+# `text` (<= 120 characters) and `kernel_name` go into the line; what they abbreviate is spelt out in profiles/BENCH_FIELDS.md.
 WORKLOADS = {
     "cfg2": dict(batch=1 << 16, steps=500, bytes=32 + 160 + 160, alg_mads=49_440, mads=97_600, seed=20002,
-                 kernel="ladder_kernel<ENDO, FUSED> (table_endo + recoding + 64 hand-scheduled ladder steps, one wave per SIMD)", unit="MUL_endo(m, P), variable base",
-                 text="BASELINE.json configs[1]: batch of 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, "
-                      "projective N-torsion points, raw R1 in/out resident in HBM"),
+                 kernel_name="ladder_kernel<ENDO,FUSED>", unit="MUL_endo(m, P), variable base",
+                 text="BASELINE.json configs[1]: 2^16 variable-base MUL_endo(m,P) per GPU, random 256-bit scalars, raw R1 in/out in HBM"),
     "cfg3": dict(batch=1 << 20, steps=60, bytes=32 + 160, alg_mads=91_264, mads=173_600, seed=30002,
-                 kernel="ladder_kernel<WINDOWED, LDS> (asm ladder bodies, two waves per SIMD)", unit="MUL_windowed(m, G, table)",
-                 text="BASELINE.json configs[2]: batch of 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table staged in LDS, raw R1 out"),
+                 kernel_name="ladder_kernel<WINDOWED,LDS>", unit="MUL_windowed(m, G, table)",
+                 text="BASELINE.json configs[2]: 2^20 fixed-base MUL_windowed(m,G,table) per GPU, table in LDS, raw R1 out"),
     # cfg4: alg_mads prices BOTH halves at the reference's algorithm (DH_endo with table_endo([392]G): 47 616; DH_endo variable
     # base: 55 072).  The keygen half actually runs the comb (6 DBL + 27 mixed ADD of 7 M: 6 x 272 + 27 x 336 = 10 704 units
     # + its share of an inversion ~ 400), so alg_mads_run = 11 104 + 55 072 is the figure comparable with the executed one.
     "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, alg_mads_run=11_104 + 55_072, mads=22_500 + 97_600 + 6_800, seed=40002,
-                 kernel="comb_kernel + ladder_kernel<ENDO, FUSED, DH, DEFER> (one launch for the eight generations, asm ladder bodies) + normalize_kernel<8>",
+                 kernel_name="comb_kernel + ladder_kernel<ENDO,FUSED,DH,DEFER> + normalize_kernel<8>",
                  unit="exchange = DH_endo(a, DH_endo(b, G)): two DH_core evaluations",
-                 text="BASELINE.json configs[3]: 2^22 dh_exchange = DH_endo(a, DH_endo(b, G)) over 8 GPUs, i.e. 2^19 exchanges per GPU "
-                      "(first half fixed-base through the 1024-point comb of [392]G, same affine outputs as with table_endo([392]G); "
-                      "second half variable-base); affine in/out"),
+                 text="BASELINE.json configs[3]: 2^22 dh_exchange over 8 GPUs = 2^19 DH_endo(a, DH_endo(b,G)) per GPU, affine in/out"),
     "cfg5": dict(batch=1 << 17, steps=300, bytes=(192 + 352) // 2, alg_mads=(41_984 + 49_440) // 2, mads=(83_300 + 97_600) // 2, seed=50002,
-                 kernel="partition_kernel + mixed_queue_kernel (one persistent kernel, one wave per SIMD pulling 64-element work items off a device-side queue: fused table_endo + asm ladder for variable-base items, the shared table for fixed-base ones)",
+                 kernel_name="partition_kernel + mixed_queue_kernel (persistent, device-side work queue)",
                  unit="MUL_endo, 50% fixed base / 50% variable base",
-                 text="BASELINE.json configs[4]: mixed batch 2^20 over 8 GPUs, i.e. 2^17 per GPU, 50% fixed-base / 50% variable-base MUL_endo; "
-                      "device-side compaction of the ids of both kinds, then BASELINE's own mechanism: a single persistent kernel whose waves "
-                      "pull work items from a device-side queue (DESIGN.md section 5)"),
+                 text="BASELINE.json configs[4]: mixed 2^20 over 8 GPUs = 2^17 per GPU, 50% fixed / 50% variable MUL_endo, persistent kernel"),
 }
+assert all(len(w["text"]) <= 120 for w in WORKLOADS.values())
 RANK_SEED_STRIDE = 16        # rank r draws from seed + 16 r (rank 0 = the seeds of SURVEY.md 8d)
 
 
@@ -79,10 +76,13 @@ def seeded_flags(seed, n):
     return (np.frombuffer(random.Random(seed).getrandbits(8 * n).to_bytes(n, "little"), dtype=np.uint8) & 1).copy()
 
 
-def host_cores(cap=True):
-    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (the GPU
-    box shows every core of the host but grants a 16-core share per GPU).  cap=False: without the 16-core ceiling of
-    one rank's share (the ranks of an N-GPU job divide what the whole job was granted)."""
+CORES_CAP = int(os.environ.get("FOURQ_BENCH_CORES", "16"))      # one rank's share of the host on the GPU boxes: 16 cores per GPU
+PER_CORE_REFERENCE_SURVEY = 410.0    # MUL_endo/s per core of the REFERENCE's own Python 2 code under python3 in the build container
+
+
+def host_cores_granted():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (the GPU box shows every core of the host
+    but grants a share of them)."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
@@ -100,7 +100,13 @@ def host_cores(cap=True):
             break
         except (OSError, ValueError, IndexError):
             continue
-    return min(cores, int(os.environ.get("FOURQ_BENCH_CORES", "16"))) if cap else cores
+    return cores
+
+
+def host_cores(cap=True):
+    """What the CPU legs USE: the granted cores, capped at CORES_CAP (one rank's share).  cap=False: the grant itself (the ranks of an
+    N-GPU job divide what the whole job was granted)."""
+    return min(host_cores_granted(), CORES_CAP) if cap else host_cores_granted()
 
 
 # ---- CPU baseline (the oracle is the checker and the thing timed here, never part of the GPU path) --------------
@@ -158,10 +164,13 @@ def cpu_baseline(kind, items, extra, expected, what, target_seconds=12.0):
     if outs != expected[:total]:
         raise SystemExit("PARITY FAILURE: GPU result differs from the oracle on the cpu_baseline sample (%s)" % what)
     busy = max(t for t, _ in results)
-    return {"value": round(total / busy, 1), "unit": "scalar-mults/s", "cores": cores, "kind": "port",
-            "sample": "%d units of the timed batch, %s via oracle/curve4q_oracle.py (pure Python big ints), %d per core on %d "
-                      "processes, %.1f s wall; outputs compared bit-exact with the GPU's" % (total, what, per_core, cores, wall),
-            "per_core": round(per_core / busy, 1)}
+    # cores = the processes actually used; the box's total, the share this process was granted and the cap are stated beside it
+    return {"value": round(total / busy, 1), "unit": "scalar-mults/s", "cores": cores, "host_cores_total": os.cpu_count(), "host_cores_granted": host_cores_granted(),
+            "cores_cap": CORES_CAP, "kind": "port",
+            "sample": "%d units of the timed batch (%s), oracle/curve4q_oracle.py, %d per core x %d processes, %.1f s wall, outputs == GPU's" % (total, what, per_core, cores, wall),
+            "per_core": round(per_core / busy, 1),
+            # the port is a baseline, never the target -- and it is faster per core than the code it restates (python3 big ints, no op counters)
+            "per_core_reference_survey": PER_CORE_REFERENCE_SURVEY}
 
 
 def c_oracle_gate(workload, data, got_words, world=1):
@@ -236,16 +245,10 @@ def valu_roofline(wl, n, kernel_ms):
            "algorithmic_mads_per_unit": wl["alg_mads"], "executed_mads_per_unit": wl["mads"],
            "algorithmic_frac": round(wl["alg_mads"] * per_s / VALU_MAD_PEAK, 4), "executed_frac": round(wl["mads"] * per_s / VALU_MAD_PEAK, 4),
            "algorithmic_frac_of_measured_peak": round(wl["alg_mads"] * per_s / VALU_MAD_PEAK_MEASURED, 4),
-           "executed_frac_of_measured_peak": round(wl["mads"] * per_s / VALU_MAD_PEAK_MEASURED, 4),
-           "note": "algorithmic = SURVEY.md 8(d) units (GF(p) mul = 16 multiply-adds on 2x64-bit limbs); executed = what the "
-                   "radix-2^26 lazy-limb layout issues (25 per GF(p) mul, no carry chains); peak = nominal 4 cycles per wave64 "
-                   "multiply-add at 2.4 GHz, peak_measured = 1.84 ns per wave64 multiply-add per SIMD sustained with every SIMD busy "
-                   "(profiles/true_rates_r01.txt)"}
-    if "alg_mads_run" in wl:                 # cfg4: the keygen half runs the comb, not the reference's 64-step ladder
+           "executed_frac_of_measured_peak": round(wl["mads"] * per_s / VALU_MAD_PEAK_MEASURED, 4)}
+    if "alg_mads_run" in wl:                 # cfg4: the keygen half runs the comb, not the reference's 64-step ladder (profiles/BENCH_FIELDS.md)
         rec["algorithmic_mads_per_unit_of_the_algorithm_run"] = wl["alg_mads_run"]
         rec["algorithmic_frac_of_the_algorithm_run"] = round(wl["alg_mads_run"] * per_s / VALU_MAD_PEAK, 4)
-        rec["note"] += "; algorithmic_frac prices both halves of an exchange at the REFERENCE's algorithm (table_endo([392]G) ladder for the " \
-                       "keygen half), ..._of_the_algorithm_run at the comb that is actually executed for it"
     return rec
 
 
@@ -303,6 +306,10 @@ class Bench:
         self.g_aff = codec.pack_point(G_aff)
         self.table_g = self.eng.table_endo(self.g1)
         self.settle_ms = float(os.environ.get("FOURQ_BENCH_SETTLE_MS", "80"))
+        self.clock_mode = os.environ.get("FOURQ_BENCH_CLOCK", "bracket")
+        if self.clock_mode == "bracket" and hasattr(self.eng, "diag_clock_begin"):
+            self.eng.diag_clock_begin()              # sizes the probe's buffers outside any timed region
+            self.eng.diag_clock_end()
 
     def to_dev(self, a):
         import numpy as np
@@ -386,24 +393,44 @@ class Bench:
         if self.world > 1:
             dist.barrier()
         GPU.synchronize()
+        # The shader clock OF the timed steps: two launches of a stamp kernel on the launch stream, one before the first
+        # timed step and one behind the last, whose waves record their CU's cycle counter and the 100 MHz counter (fourq_diag_clock_begin /
+        # _stop; paired per CU by _end).  Both lie OUTSIDE the two events; nothing stays resident beside the steps and the product kernels
+        # carry no stamp.  FOURQ_BENCH_CLOCK=after|off: the round-5 probe on a backlog behind the timed region / none.
+        bracket = self.clock_mode == "bracket" and hasattr(self.eng, "diag_clock_begin")
         t0 = time.perf_counter()
+        if bracket:
+            self.eng.diag_clock_begin()
         ev0.record(self.stream)                      # HIP events on the launch stream, around the K timed steps
         for _ in range(steps):
             step()
         ev1.record(self.stream)
+        if bracket:
+            self.eng.diag_clock_stop()               # enqueues; the host does not wait here
         GPU.synchronize()
         if self.world > 1:
             dist.barrier()
         GPU.synchronize()
         elapsed = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / max(1, steps)      # average launch duration, inter-launch gaps included
+        clock = None
+        if bracket:
+            c = self.eng.diag_clock_end()
+            # the window must be the timed region and nothing else: within 2 % + 0.2 ms of the events' span
+            span_ms = kernel_ms * steps
+            covered = c["window_us"] * 1e-3 / span_ms if span_ms > 0 else 0.0
+            clock = {"in_kernel_mhz": round(c["mhz"], 1), "min_mhz": round(c["mhz_min"], 1), "max_mhz": round(c["mhz_max"], 1),
+                     "window_ms": round(c["window_us"] * 1e-3, 3), "mode": "bracket", "window_over_timed_span": round(covered, 4),
+                     "valid": bool(abs(c["window_us"] * 1e-3 - span_ms) <= 0.02 * span_ms + 0.2)}
         if self.world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.rehearse else self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         if workload == "cfg4" and (bool(d["status"][0].any()) or bool(d["status"][1].any())):
             raise SystemExit("cfg4: unexpected DH failure status")
-        clock = self.clock_under_load(step, kernel_ms)           # a diagnostic launch AFTER the timed region: nothing of it is in `elapsed`
+        if clock is None and self.clock_mode != "off":
+            clock = self.clock_under_load(step, kernel_ms)       # a diagnostic launch AFTER the timed region: nothing of it is in `elapsed`
+        usable = bool(clock) and clock.get("valid", True)
         total = n * self.world * steps
         ach_gbs = wl["bytes"] * n / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = _pmc_traffic(workload, self.eng.build_id)
@@ -414,14 +441,13 @@ class Bench:
             "roofline": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_gbs / HBM_PEAK_GBS, 6),
                          "traffic": None if self.eng.ct_select else traffic, "traffic_source": traffic_src,     # the PMC passes ran on the default kernels
-                         "kernel": wl["kernel"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n,
-                         "note": "the path is integer-VALU bound, not HBM bound (SURVEY.md 8d): see valu_roofline"},
+                         "kernel": wl["kernel_name"], "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": wl["bytes"] * n},
             "valu_roofline": valu_roofline(wl, n, kernel_ms),
             # What makes this line comparable across boxes: MI355X devices hold clocks several percent apart under the
             # same kernel, so the same code gives 2.14 - 2.24 x 10^8/s on different boxes; in cycles they agree.
             "clock": clock,
-            "cycles_per_unit": None if not clock else round(kernel_ms * 1e-3 * clock["in_kernel_mhz"] * 1e6 / n, 3),
-            "kernel_cycles_per_step": None if not clock else round(kernel_ms * 1e-3 * clock["in_kernel_mhz"] * 1e6, 0),
+            "cycles_per_unit": None if not usable else round(kernel_ms * 1e-3 * clock["in_kernel_mhz"] * 1e6 / n, 3),
+            "kernel_cycles_per_step": None if not usable else round(kernel_ms * 1e-3 * clock["in_kernel_mhz"] * 1e6, 0),
         }
         # The bound that actually holds (round 4, profiles/r04_ladder_step.txt): with every 8-byte instruction 8-byte aligned a SIMD issues
         # ONE wave64 VALU instruction per ~4 cycles for this instruction mix, multiply-add or not, at one, two or four waves per SIMD.
@@ -432,15 +458,13 @@ class Bench:
             "wave_instructions_per_step": wave_instr, "instructions_per_unit": None if wave_instr is None else round(wave_instr * 64 / n, 1),
             "achieved": None if wave_instr is None else round(wave_instr / (kernel_ms * 1e-3) / 1e9, 1),
             "frac": None if wave_instr is None else round(wave_instr / (kernel_ms * 1e-3) / issue_peak, 4),
-            "source": "SQ_INSTS_VALU of the step's kernels, profiles/pmc_traffic.json (same build-id rule as roofline.traffic)",
-            "note": "what is left on this path is the instruction count per unit, not the schedule, the occupancy or the memory system"}
+            "source": "profiles/pmc_traffic.json"}
         return rec, d
 
     def clock_under_load(self, step, kernel_ms, window_ms=25.0):
-        """The shader clock while THIS workload runs, from inside a kernel (MI355X_MICROARCH 'DVFS give-back' item 6): the stream gets a
-        backlog of steps three windows long (the _dev calls only enqueue), and while it drains a 16-wave probe on another stream of the
-        context times `window_ms` of the 100 MHz counter in shader cycles (fourq_diag_clock).  The probe's waves sleep; the product
-        kernels carry no stamp.  Runs right after the timed steps, so the governor is in the state the timed steps saw."""
+        """Round 5's form of the clock probe (FOURQ_BENCH_CLOCK=after): the stream gets a backlog of steps three windows long (the _dev calls
+        only enqueue), and while it drains the probe times `window_ms` on a side stream (fourq_diag_clock).  `valid` is False when the
+        stream had already drained when the window closed -- the reading is then an idle chip's."""
         if not hasattr(self.eng, "diag_clock"):
             return None
         backlog = max(4, int(3.0 * window_ms / max(kernel_ms, 1e-3)) + 1)
@@ -449,10 +473,7 @@ class Bench:
         c = self.eng.diag_clock(int(window_ms * 1000))
         GPU.synchronize()
         return {"in_kernel_mhz": round(c["mhz"], 1), "min_mhz": round(c["mhz_min"], 1), "max_mhz": round(c["mhz_max"], 1), "window_ms": window_ms,
-                "steps_queued_behind_the_probe": backlog,
-                "how": "s_memtime / s_memrealtime x 100 MHz over the window, 16 probe waves (two per XCD) on a side stream while the "
-                       "workload's kernels run back to back (fourq_diag_clock); cycles_per_unit = kernel_ms x this clock / batch_per_gpu = "
-                       "shader cycles of the whole chip per unit of work"}
+                "mode": "after", "steps_queued_behind_the_probe": backlog, "valid": bool(c.get("under_load", True))}
 
     def parity_gate(self, workload, d):
         """Every output of this rank's shard against the C oracle; raises on any difference."""
@@ -746,12 +767,6 @@ class Bench:
                     raise SystemExit("PARITY FAILURE: host-array path (cfg2 x 16, %s I/O) differs from the C oracle" % label)
                 rec["at_2^20"][label] = {"value": round(big / dt, 1), "ms_per_step": round(dt * 1e3, 3), "best_ms": round(best * 1e3, 3), "chunks": eng.host_stats()["chunks"],
                                          "wall_gbs_both_directions": round(big * nbytes / dt / 1e9, 2)}
-        rec["note"] = ("value = units / MEDIAN wall-clock of the synchronous host-array call, timed call by call after the device has been brought "
-                       "to its sustained clock by repeating the call for clock_settle_ms, as the device-resident steps are (H2D, kernels, D2H pipelined over chunks of whole "
-                       "kernel generations, fourq_amd/csrc/pipeline_plan.h); gbs_* = bytes / summed copy durations of ONE EXTRA call made under "
-                       "fourq_ctx_set_host_timing (HIP events on the copy streams), i.e. the link rate while a copy is running; kernel_stream_* = "
-                       "that call's kernel stream: busy with the chunks' kernels, and from the first chunk's start to the last chunk's end; every "
-                       "output compared with the C oracle")
         for a in pins:
             eng.host_free(a)
         return rec
@@ -790,10 +805,9 @@ def _pmc_traffic(workload, build_id):
     except (OSError, ValueError):
         return None, {"file": None, "note": "profiles/pmc_traffic.json not found"}
     profiled = (data.get("library_build_ids") or {}).get(workload, data.get("library_build_id"))
-    src = {"file": "profiles/pmc_traffic.json <- %s" % data.get("source"), "profiled_library_build_id": profiled,
-           "loaded_library_build_id": build_id, "method": data.get("note")}
+    src = {"file": "profiles/pmc_traffic.json <- %s" % data.get("source"), "profiled_library_build_id": profiled, "loaded_library_build_id": build_id}
     if not build_id or profiled != build_id:
-        src["note"] = "the committed PMC profile was taken on another build of the library: no traffic figure is claimed for this one"
+        src["claimed"] = False          # the committed PMC profile was taken on another build of the library: no traffic figure for this one
         return None, src
     return (data.get("per_workload") or {}).get(workload), src
 
@@ -821,6 +835,110 @@ def _built_from_sources():
         return None
 
 
+# ---- what is printed ---------------------------------------------------------------------------------------------
+LINE_MAX_BYTES = 6144        # the driver reads the tail of stdout: the line must stay far below what it keeps (22 KB was not parsed)
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_config(rec, ct=None):
+    """One flat, numbers-only record (<= 300 bytes) of a workload's full record."""
+    out = {"value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "kernel_ms": _get(rec, "roofline", "kernel_ms"),
+           "roofline_frac": _get(rec, "roofline", "frac"), "algorithmic_frac": _get(rec, "valu_roofline", "algorithmic_frac"),
+           "issue_frac": _get(rec, "valu_roofline", "issue", "frac"), "cycles_per_unit": rec.get("cycles_per_unit"),
+           "parity_ok": _get(rec, "parity", "ok"), "pcie_value": _get(rec, "pcie_inclusive", "value"),
+           "ct_ratio": None if not ct else ct.get("ratio_vs_default")}
+    if rec.get("gather_ms") is not None:
+        out["gather_ms"] = rec["gather_ms"]
+    return out
+
+
+def compact_line(full):
+    """The ONE line of stdout: the contract keys and numbers only, <= LINE_MAX_BYTES.  Every field is defined in profiles/BENCH_FIELDS.md;
+    the full record (every nested measurement) goes to stderr and to bench_full.json."""
+    cfg, roof, valu = full["config"], full["roofline"], full["valu_roofline"]
+    ct = full.get("ct_select") or {}
+    head = next((w for w in WORKLOADS if WORKLOADS[w]["text"] == cfg["workload"]), "cfg2")
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": cfg["workload"][:120], "batch_per_gpu": cfg["batch_per_gpu"], "ranks_seen": cfg["ranks_seen"], "backend": cfg["backend"],
+                      "build_id": _get(cfg, "library", "build_id"), "built_from_sources": _get(cfg, "library", "built_from_these_sources"),
+                      "table_selection": cfg["table_selection"]}
+    line["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch")}
+    line["valu_roofline"] = {"peak": valu["peak"], "unit": valu["unit"], "algorithmic_frac": valu["algorithmic_frac"], "executed_frac": valu["executed_frac"],
+                             "issue_frac": _get(valu, "issue", "frac")}
+    line["clock_mhz"] = _get(full, "clock", "in_kernel_mhz")
+    line["cycles_per_unit"] = full.get("cycles_per_unit")
+    line["parity_ok"] = _get(full, "parity", "all_ranks_ok") if full["n_gpus"] > 1 else _get(full, "parity", "ok")
+    if "cycles_per_unit_ranks" in full:
+        line["cycles_per_unit_ranks"] = full["cycles_per_unit_ranks"]
+    if "gather_ms" in full:
+        line["gather_ms"] = full["gather_ms"]
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "host_cores_total": cb["host_cores_total"],
+                                "host_cores_granted": cb["host_cores_granted"], "cores_cap": cb["cores_cap"], "kind": cb["kind"], "per_core": cb["per_core"],
+                                "per_core_reference_survey": cb["per_core_reference_survey"], "c_restatement_value": _get(cb, "c_restatement", "value"),
+                                "sample": cb["sample"][:160]}
+    if head in ct:
+        line["ct_value"], line["ct_ratio"] = ct[head]["value"], ct[head]["ratio_vs_default"]
+    if "alongside" in full:
+        line["alongside_value"] = full["alongside"]["value_per_gpu"]
+    p = full.get("pcie_inclusive")
+    if p:
+        big = p.get("at_2^20") or {}
+        line["pcie"] = {"value": p["value"], "ms": p["ms_per_step"], "pageable_ms": _get(p, "pageable_caller", "ms_per_step"),
+                        "affine_ms": _get(p, "affine", "ms_per_step"), "bytes_ms": _get(p, "bytes", "ms_per_step"),
+                        "r1_2p20_ms": _get(big, "r1", "ms_per_step"), "affine_2p20_ms": _get(big, "affine", "ms_per_step"), "bytes_2p20_ms": _get(big, "bytes", "ms_per_step"),
+                        "ct_r1_2p20_ms": _get(big, "ct_r1", "ms_per_step"), "ct_floor_2p20_ms": _get(big, "ct_r1", "floor_ms")}
+    if "configs" in full:
+        line["configs"] = {w: compact_config(r, ct.get(w)) for w, r in sorted(full["configs"].items())}
+    line["full_record"] = full.get("full_record")
+    line["fields"] = "profiles/BENCH_FIELDS.md"
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_MAX_BYTES:
+        raise SystemExit("bench.py: the result line is %d bytes, over the %d the driver is known to read" % (len(text), LINE_MAX_BYTES))
+    return text
+
+
+def emit(full, full_json):
+    """Full record -> stderr and `full_json`; then the compact line, alone, on stdout."""
+    full["full_record"] = os.path.relpath(full_json, ROOT) if full_json else None
+    blob = json.dumps(full)
+    if full_json:
+        try:
+            with open(full_json, "w") as fh:
+                fh.write(blob + "\n")
+        except OSError as exc:                      # a read-only tree: the record is still on stderr
+            full["full_record"] = None
+            print("bench.py: could not write %s (%s)" % (full_json, exc), file=sys.stderr)
+    print(blob, file=sys.stderr, flush=True)
+    text = compact_line(full)
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(text, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+
+
+_REAL_STDOUT = None
+
+
+def stdout_is_for_the_line_only():
+    """From here on file descriptor 1 of this process IS its stderr: whatever a library prints on stdout (gloo's connection banner, a
+    runtime's notices) cannot end up beside the result line.  emit() writes the line to the real stdout kept aside here."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 # ---- launcher ----------------------------------------------------------------------------------------------------
 def self_launch(args, argv):
     """`bench.py --gpus N` from a bare shell: N fresh rank processes under torch.distributed.run.  This process never
@@ -829,6 +947,8 @@ def self_launch(args, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
+    # The pool's host driver supports dmabuf IPC only: without this RCCL's (and torch's) cross-process buffer sharing fails with
+    # "hipIpcGetMemHandle: invalid argument".  The GPU boxes export it already (the build environment's own note); a bare shell may not.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, min(host_cores(), host_cores(cap=False) // args.gpus))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -853,6 +973,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive host-array measurement")
     ap.add_argument("--no-alongside", action="store_true", help="skip the second operation SURVEY.md 8(d) reports alongside cfg2 / cfg3")
     ap.add_argument("--no-parity", action="store_true", help="profiling runs only: skip the whole-shard C-oracle gate")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"), help="where the full record goes (also printed on stderr); '' = nowhere")
     ap.add_argument("--no-ct", action="store_true", help="skip the constant-time-selection records (second context, FOURQ_CT_SELECT mode)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -860,6 +981,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    stdout_is_for_the_line_only()
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -876,7 +998,10 @@ def main():
     GPU.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world)
+        import datetime
+        # a rank that dies (its parity gate raises) must take the job down, not leave the others waiting for ever
+        dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("FOURQ_BENCH_PG_TIMEOUT_S", "600"))))
     b = Bench(rank, local_rank, world, rehearse)
 
     wl = WORKLOADS[args.workload]
@@ -916,63 +1041,66 @@ def main():
         if do_ct:
             ct[w] = b.ct_select_record(w, WORKLOADS[w]["batch"], max(5, WORKLOADS[w]["steps"] // 5), 2, want_w, r["ms_per_step"])
 
-    ranks_seen = 1
+    ranks_seen, cyc_range = 1, None
     if world > 1:                                           # every rank passed its own gate, or the job has already died
-        ok = torch.tensor([1.0 if parity["ok"] in (True, None) else 0.0], device="cpu" if rehearse else b.dev)
+        where = "cpu" if rehearse else b.dev
+        ok = torch.tensor([1.0 if parity["ok"] in (True, None) else 0.0], device=where)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         parity["all_ranks_ok"] = bool(ok.item() == 1.0)
-        here = torch.tensor([1.0], device="cpu" if rehearse else b.dev)      # counted, not assumed: one from every rank that got this far
+        # ranks_seen is a record, not a guard: a rank that died makes the collectives above fail or time out (init_process_group's
+        # timeout), and this process then exits non-zero without a line (tests/test_dist.py)
+        here = torch.tensor([1.0], device=where)
         dist.all_reduce(here, op=dist.ReduceOp.SUM)
         ranks_seen = int(round(here.item()))
-        # No line unless the job is whole: a value summed over fewer ranks than --gpus, or over a rank whose outputs
-        # were not checked against the oracle, is not a measurement of `--gpus N`.
         if ranks_seen != args.gpus or not parity["all_ranks_ok"]:
             raise SystemExit("bench.py --gpus %d: %d ranks reported, all_ranks_ok=%s -- no result line is printed for an incomplete job"
                              % (args.gpus, ranks_seen, parity["all_ranks_ok"]))
+        cyc = rec["cycles_per_unit"] or 0.0                                     # per-rank cycles per unit: the spread over the node's devices
+        lo, hi = torch.tensor([cyc if cyc else 1e30], dtype=torch.float64, device=where), torch.tensor([cyc], dtype=torch.float64, device=where)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        cyc_range = [round(float(lo.item()), 3) if lo.item() < 1e29 else None, round(float(hi.item()), 3) or None]
     if rank == 0:
-        line = {
+        full = {
             "metric": "FourQ scalar-mults/sec (batch, whole node)", "value": rec["value"], "unit": rec["unit"],
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": rec["workload"], "batch_per_gpu": n, "parallelism": "independent shards x%d, no data-path collective" % world,
-                       "clock_settle_ms": b.settle_ms, "table_selection": "constant-time (every entry read, FOURQ_CT_SELECT=1)" if b.eng.ct_select
-                       else "as the reference (default): digit = table address (curve4q.py:232, :440), sign = masked select (curve4q.py:193-206); "
-                            "not constant-time in the digit -- see ct_select for the mode that is",
+                       "clock_settle_ms": b.settle_ms, "table_selection": "constant-time" if b.eng.ct_select else "indexed",
                        "library": {"version": b.eng.version, "build_id": b.eng.build_id, "built_from_these_sources": _built_from_sources()},
                        "ranks_seen": ranks_seen,
                        "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if world > 1 else None},
             "roofline": rec["roofline"], "valu_roofline": rec["valu_roofline"], "parity": parity,
             "clock": rec["clock"], "cycles_per_unit": rec["cycles_per_unit"], "kernel_cycles_per_step": rec["kernel_cycles_per_step"],
+            "fields": "profiles/BENCH_FIELDS.md",
         }
-        if args.workload == "cfg4":
-            line["config"]["note"] = "one unit = one exchange = two DH_core evaluations"
+        if cyc_range is not None:
+            full["cycles_per_unit_ranks"] = cyc_range
         if gather is not None:
-            line["gather_ms"] = gather
-            line["config"]["gather"] = "results of all ranks gathered to rank 0 (fourq_amd.dist.gather_rows), untimed in `value`, median of 3"
+            full["gather_ms"] = gather
         if alongside is not None:
-            line["alongside"] = alongside
+            full["alongside"] = alongside
         if configs:
-            line["configs"] = configs
+            full["configs"] = configs
         if world == 1 and not args.no_pcie and want is not None:
-            line["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=pcie_reps[args.workload])
+            full["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=pcie_reps[args.workload])
         if world == 1 and args.workload == "cfg2" and not args.batch and not args.no_alongside:
-            line["size_sweep"] = b.size_sweep(d)
+            full["size_sweep"] = b.size_sweep(d)
             if not args.no_parity:
-                line["small_batches"] = b.small_batches(d)
+                full["small_batches"] = b.small_batches(d)
         if ct:
-            line["ct_select"] = dict(ct, mode="fourq_ctx_set_ct_select(ctx, 1) on a second context: every ladder step reads the whole table and "
-                                              "selects by masks; no address depends on the scalar (DESIGN.md section 10); outputs compared with the "
-                                              "same C-oracle results as the default mode")
-        if not args.no_cpu_baseline and got is not None:
+            full["ct_select"] = ct
+        # The CPU baseline is an N = 1 figure (rank 0, alone on the host): at N > 1 the other ranks' oracle gates would share its cores
+        if world == 1 and not args.no_cpu_baseline and got is not None:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             sample = min(n, 1 << 16)
             items, extra, what = cpu_items(args.workload, d, sample)
-            line["cpu_baseline"] = cpu_baseline(args.workload, items, extra, codec.unpack_points(got[:sample]), what)
-            line["cpu_baseline"]["c_restatement"] = {
+            full["cpu_baseline"] = cpu_baseline(args.workload, items, extra, codec.unpack_points(got[:sample]), what)
+            full["cpu_baseline"]["c_restatement"] = {
                 "value": parity["c_oracle_units_per_s"], "unit": "scalar-mults/s", "threads": parity["c_oracle_threads"], "cores": host_cores(), "kind": "port",
                 "sample": "whole batch (%d units) via oracle/fourq_oracle.c (OpenMP), every output compared bit-exact with the GPU's" % n}
-            line["cpu_baseline"]["sample"] += "; plus %d edge-case scalar/point pairs (0, 1, 2, N-1, N, N+1, 2N, 2^255, 2^256-1 on +-G), exact" % edge_case_check(b.eng)
-        print(json.dumps(line), flush=True)
+            full["cpu_baseline"]["edge_cases_checked"] = edge_case_check(b.eng)
+        emit(full, args.full_json)
     if getattr(b, "eng_ct", None) is not None:
         b.eng_ct.close()
     b.eng.close()

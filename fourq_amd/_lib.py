@@ -21,7 +21,7 @@ DH_OK, DH_NOT_ON_CURVE, DH_NEUTRAL = 0, 1, 2
 DECODE_OK, DECODE_RESERVED_BIT, DECODE_NOT_ON_CURVE, DECODE_REF_ATTRIBUTE_ERROR = 0, 1, 2, 3
 
 MAX_BATCH = 0xFFFFFF00
-ABI_VERSION = 500                    # fourq_version(): 0.5.0 (round 5: fourq_ctx_set_host_timing, fourq_diag_clock; 0.4.0 added fourq_mul_*_{affine,bytes}_batch)
+ABI_VERSION = 600                    # fourq_version(): 0.6.0 (round 6: fourq_diag_clock_{begin,stop,end}, under_load; 0.5.0: fourq_ctx_set_host_timing, fourq_diag_clock)
 COMB_POINTS = 1024 + 80              # FOURQ_COMB_POINTS: the fast comb and the one the constant-time mode scans
 COMB_WORDS = COMB_POINTS * 12        # FOURQ_COMB_WORDS
 BYTES_DECODE_BASE = 16
@@ -54,8 +54,12 @@ PROTOTYPES = {
     "fourq_host_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "fourq_host_free": (c_int, [c_void_p, c_void_p]),
     "fourq_ctx_host_stats": (c_int, [c_void_p, c_void_p]),
+    "fourq_ctx_host_stats_sized": (c_int, [c_void_p, c_void_p, c_size_t]),
     "fourq_ctx_set_host_timing": (c_int, [c_void_p, c_int]),
-    "fourq_diag_clock": (c_int, [c_void_p, ctypes.c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "fourq_diag_clock": (c_int, [c_void_p, ctypes.c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
+    "fourq_diag_clock_begin": (c_int, [c_void_p]),
+    "fourq_diag_clock_stop": (c_int, [c_void_p]),
+    "fourq_diag_clock_end": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "fourq_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "fourq_dev_free": (c_int, [c_void_p, c_void_p]),
     "fourq_dev_upload": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),

@@ -25,10 +25,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <functional>
 #include <mutex>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #ifndef FQ_CHAIN
@@ -306,6 +308,20 @@ __global__ __launch_bounds__(64) void clock_probe_kernel(u64* stamps, u64 ticks)
     if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// The bracket form (fourq_diag_clock_begin / _stop / _end): NO probe stays resident beside the work -- a sleeping wave still holds eight
+// registers of its SIMD, and a kernel that fills the register file (the LDS-table ladders: 2 x 256 VGPRs per SIMD) then loses a whole
+// workgroup slot on that CU: config 3 ran 30 % slower under the round-6 first attempt (profiles/r06_clock_probe.txt).  Instead two launches
+// of this kernel ON THE CONTEXT'S STREAM, one before and one after the bracketed work, each wave recording its CU's cycle counter and the
+// global 100 MHz counter.  s_memtime is a PER-CU counter (tools/microbench/stamp_coherence.hip: 256 CUs, each coherent within 113 cycles,
+// offsets between CUs up to 4 x 10^7), so the host pairs the two launches' stamps CU by CU (key = XCC_ID, and SE / SH / CU of HW_ID).
+__global__ __launch_bounds__(64) void clock_stamp_kernel(u64* stamps) {
+    u64 t, r;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r) :: "memory");
+    const u32 xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15;        // HW_REG_XCC_ID[3:0]
+    const u32 hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) & 0xFF00;      // HW_REG_HW_ID: cu 11:8, sh 12, se 15:13
+    if (threadIdx.x == 0) { u64* o = stamps + 3 * (size_t)blockIdx.x; o[0] = (u64)xcc << 16 | hw; o[1] = t; o[2] = r; }
+}
+
 __global__ __launch_bounds__(BLOCK) void merge_status_kernel(const uint8_t* first, uint8_t* status, u32 n) {
     u32 i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < n && first[i]) status[i] = first[i];
@@ -483,6 +499,9 @@ struct fourq_ctx {
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
     u64* diag_stamps = nullptr;    // fourq_diag_clock: 2 x 16 stamps, allocated at its first call
+    u64* diag_bracket = nullptr;   // fourq_diag_clock_begin / _stop: 2 x DIAG_STAMP_BLOCKS x {CU key, memtime, memrealtime}
+    bool diag_open = false;        // the first stamp launch of a bracket has been enqueued
+    bool diag_stopped = false;     // ... and the second
     char* zero_copy = nullptr;     // 64 KiB of pinned host memory the kernels of a TINY host call read and write directly (no copy engine)
     fourq_host_stats host_stats = {};
     bool host_bounce = true;       // FOURQ_HOST_BOUNCE=0: hand pageable arrays to hipMemcpyAsync directly (measurement knob)
@@ -760,7 +779,7 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
 // nothing can overlap, and (b) whatever keeps the kernel stream waiting between chunks.  So: the FIRST and the LAST chunk are one generation
 // (the smallest unit that fills the chip), the chunks in between `pipe_gens` generations (fewer stream hops per element); a slot is handed
 // on ON THE GPU -- the copy-in stream waits for the event behind the slot's previous copy-out -- so the host enqueues every chunk without
-// ever blocking and the queues never run dry because the host was asleep in hipEventSynchronize; and the four timing events per chunk
+// ever blocking and the queues never run dry because the host was asleep in hipEventSynchronize; and the six timing events per chunk
 // are recorded only when the caller asked for copy durations (fourq_ctx_set_host_timing).  Pageable callers keep the host-side hand-over:
 // their bounce slots are filled and drained by the host anyway.
 constexpr int PIPE_MAX_ARRAYS = 4;
@@ -1096,7 +1115,7 @@ extern "C" {
 
 #define FQ_API __attribute__((visibility("default")))
 
-FQ_API int fourq_version(void) { return 500; }    // 0.5.0; fourq_amd/_lib.py checks it at load time
+FQ_API int fourq_version(void) { return 600; }    // 0.6.0; fourq_amd/_lib.py checks it at load time
 #ifndef FQ_BUILD_ID
 #define FQ_BUILD_ID "unknown"
 #endif
@@ -1235,6 +1254,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->pipe_pin) (void)hipHostFree(c->pipe_pin);
     if (c->zero_copy) (void)hipHostFree(c->zero_copy);
     if (c->diag_stamps) (void)hipFree(c->diag_stamps);
+    if (c->diag_bracket) (void)hipFree(c->diag_bracket);
     if (c->shadow_read) (void)hipEventDestroy(c->shadow_read);
     for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
     for (int i = 0; i < PIPE_SLOTS_MAX; i++) {
@@ -1792,27 +1812,119 @@ FQ_API int fourq_ctx_set_host_timing(fourq_ctx* c, int on) {
 // single-wave blocks on a stream of the context's own (not the one its kernels are enqueued on), each timing `window_us` of the 100 MHz
 // counter in shader cycles.  Call it while the context's stream has work queued for longer than the window (the _dev calls only enqueue)
 // and the answer is the clock under THAT load: what turns a time measured on one box into cycles comparable with another's.
-FQ_API int fourq_diag_clock(fourq_ctx* c, uint32_t window_us, double* mhz_median, double* mhz_min, double* mhz_max) {
-    if (!c || !mhz_median || window_us == 0 || window_us > 1000000) return FOURQ_ERR_INVALID;
-    CtxGuard g(c);
-    constexpr int BLOCKS = 16;                          // consecutive workgroups go to consecutive XCDs: two probes on each of the eight
-    if (!c->diag_stamps) HIP_TRY(c, hipMalloc(&c->diag_stamps, 2 * BLOCKS * sizeof(u64)));      // kept: hipFree would wait for the whole device
-    u64 host[2 * BLOCKS];
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(BLOCKS), dim3(64), 0, c->copy_out, c->diag_stamps, (u64)window_us * 100u);
-    HIP_TRY(c, hipGetLastError());
+namespace {
+constexpr int DIAG_BLOCKS = 16;                     // consecutive workgroups go to consecutive XCDs: two probes on each of the eight
+int diag_alloc(fourq_ctx* c) {
+    if (!c->diag_stamps) HIP_TRY(c, hipMalloc(&c->diag_stamps, 2 * DIAG_BLOCKS * sizeof(u64)));      // kept: hipFree would wait for the whole device
+    return FOURQ_OK;
+}
+int diag_reduce(fourq_ctx* c, double* mhz_median, double* mhz_min, double* mhz_max, double* window_us) {
+    u64 host[2 * DIAG_BLOCKS];
     HIP_TRY(c, hipMemcpyAsync(host, c->diag_stamps, sizeof host, hipMemcpyDeviceToHost, c->copy_out));
     HIP_TRY(c, hipStreamSynchronize(c->copy_out));
-    double mhz[BLOCKS];
-    for (int i = 0; i < BLOCKS; i++) mhz[i] = host[2 * i + 1] ? (double)host[2 * i] / ((double)host[2 * i + 1] / 100.0) : 0.0;
-    for (int i = 1; i < BLOCKS; i++) for (int j = i; j > 0 && mhz[j] < mhz[j - 1]; j--) { const double t = mhz[j]; mhz[j] = mhz[j - 1]; mhz[j - 1] = t; }
-    *mhz_median = 0.5 * (mhz[BLOCKS / 2 - 1] + mhz[BLOCKS / 2]);
+    double mhz[DIAG_BLOCKS], win = 0.0;
+    for (int i = 0; i < DIAG_BLOCKS; i++) {
+        mhz[i] = host[2 * i + 1] ? (double)host[2 * i] / ((double)host[2 * i + 1] / 100.0) : 0.0;
+        win += (double)host[2 * i + 1] / 100.0 / DIAG_BLOCKS;
+    }
+    for (int i = 1; i < DIAG_BLOCKS; i++) for (int j = i; j > 0 && mhz[j] < mhz[j - 1]; j--) { const double t = mhz[j]; mhz[j] = mhz[j - 1]; mhz[j - 1] = t; }
+    *mhz_median = 0.5 * (mhz[DIAG_BLOCKS / 2 - 1] + mhz[DIAG_BLOCKS / 2]);
     if (mhz_min) *mhz_min = mhz[0];
-    if (mhz_max) *mhz_max = mhz[BLOCKS - 1];
+    if (mhz_max) *mhz_max = mhz[DIAG_BLOCKS - 1];
+    if (window_us) *window_us = win;
+    return FOURQ_OK;
+}
+}  // namespace
+FQ_API int fourq_diag_clock(fourq_ctx* c, uint32_t window_us, double* mhz_median, double* mhz_min, double* mhz_max, int* under_load) {
+    if (!c || !mhz_median || window_us == 0 || window_us > 1000000) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
+    if (int rc = diag_alloc(c)) return rc;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(DIAG_BLOCKS), dim3(64), 0, c->copy_out, c->diag_stamps, (u64)window_us * 100u);
+    HIP_TRY(c, hipGetLastError());
+    int rc = diag_reduce(c, mhz_median, mhz_min, mhz_max, nullptr);
+    // Was the context's stream still busy when the window closed?  If the probe shared a hardware queue with the kernels it waited
+    // behind them and timed an idle chip: the caller must be able to tell.
+    if (under_load) *under_load = hipStreamQuery(c->stream) == hipErrorNotReady ? 1 : 0;
+    return rc;
+}
+// The bracket form: begin and stop each enqueue one launch of clock_stamp_kernel on the context's stream -- before and behind the work the
+// caller enqueues in between, so the host never waits; end waits for the stream, pairs the stamps per CU and reduces.
+namespace {
+constexpr int DIAG_STAMP_BLOCKS = 1024;             // single-wave workgroups: about four per CU, so that (nearly) every CU is in both launches
+int diag_stamp(fourq_ctx* c, int which) {
+    if (!c->diag_bracket) HIP_TRY(c, hipMalloc(&c->diag_bracket, 2 * 3 * DIAG_STAMP_BLOCKS * sizeof(u64)));
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(DIAG_STAMP_BLOCKS), dim3(64), 0, c->stream, c->diag_bracket + (size_t)which * 3 * DIAG_STAMP_BLOCKS);
+    HIP_TRY(c, hipGetLastError());
+    return FOURQ_OK;
+}
+}  // namespace
+FQ_API int fourq_diag_clock_begin(fourq_ctx* c) {
+    if (!c) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
+    if (c->diag_open) return FOURQ_ERR_INVALID;
+    if (int rc = diag_stamp(c, 0)) return rc;
+    c->diag_open = true;
+    c->diag_stopped = false;
+    return FOURQ_OK;
+}
+FQ_API int fourq_diag_clock_stop(fourq_ctx* c) {
+    if (!c) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
+    if (!c->diag_open || c->diag_stopped) return FOURQ_ERR_INVALID;
+    if (int rc = diag_stamp(c, 1)) return rc;
+    c->diag_stopped = true;
+    return FOURQ_OK;
+}
+FQ_API int fourq_diag_clock_end(fourq_ctx* c, double* mhz_median, double* mhz_min, double* mhz_max, double* window_us) {
+    if (!c || !mhz_median) return FOURQ_ERR_INVALID;
+    CtxGuard g(c);
+    if (!c->diag_open) return FOURQ_ERR_INVALID;
+    if (!c->diag_stopped) { if (int rc = diag_stamp(c, 1)) return rc; }
+    c->diag_open = c->diag_stopped = false;
+    std::vector<u64> h;
+    try { h.resize(2 * 3 * DIAG_STAMP_BLOCKS); } catch (...) { return FOURQ_ERR_NOMEM; }
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->diag_bracket, h.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // one (memtime, memrealtime) pair per CU and launch -- the first block that landed on it; then per CU seen in both: cycles per 10 ns
+    const u64 *a = h.data(), *b = h.data() + 3 * DIAG_STAMP_BLOCKS;
+    std::vector<double> mhz;
+    double win = 0.0;
+    try {
+        std::vector<std::pair<u64, int>> first;          // (CU key, block of the first launch)
+        for (int i = 0; i < DIAG_STAMP_BLOCKS; i++) first.emplace_back(a[3 * i], i);
+        std::sort(first.begin(), first.end());
+        std::vector<bool> used(DIAG_STAMP_BLOCKS, false);
+        for (int j = 0; j < DIAG_STAMP_BLOCKS; j++) {
+            auto it = std::lower_bound(first.begin(), first.end(), std::make_pair(b[3 * j], 0));
+            if (it == first.end() || it->first != b[3 * j]) continue;
+            const int slot = (int)(it - first.begin());
+            if (used[slot]) continue;                    // this CU is paired already
+            used[slot] = true;
+            const int i = it->second;
+            const double ticks = (double)(b[3 * j + 2] - a[3 * i + 2]);
+            if (ticks <= 0) continue;
+            mhz.push_back((double)(b[3 * j + 1] - a[3 * i + 1]) / (ticks / 100.0));
+            win += ticks / 100.0;
+        }
+    } catch (...) { return FOURQ_ERR_NOMEM; }
+    if (mhz.size() < 8) { snprintf(c->err, sizeof c->err, "fourq_diag_clock_end: only %zu CUs were stamped by both launches", mhz.size()); return FOURQ_ERR_HIP; }
+    std::sort(mhz.begin(), mhz.end());
+    const size_t m = mhz.size();
+    *mhz_median = 0.5 * (mhz[(m - 1) / 2] + mhz[m / 2]);
+    if (mhz_min) *mhz_min = mhz[m / 20];                 // 5th and 95th percentile over the CUs: the spread of the chip's clock domains, not of stragglers
+    if (mhz_max) *mhz_max = mhz[m - 1 - m / 20];
+    if (window_us) *window_us = win / (double)m;
     return FOURQ_OK;
 }
 FQ_API int fourq_ctx_host_stats(const fourq_ctx* c, fourq_host_stats* out) {
     if (!c || !out) return FOURQ_ERR_INVALID;
     *out = c->host_stats;
+    return FOURQ_OK;
+}
+
+FQ_API int fourq_ctx_host_stats_sized(const fourq_ctx* c, void* out, size_t size) {
+    if (!c || !out) return FOURQ_ERR_INVALID;
+    memcpy(out, &c->host_stats, size < sizeof c->host_stats ? size : sizeof c->host_stats);
     return FOURQ_OK;
 }
 

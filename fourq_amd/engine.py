@@ -132,10 +132,25 @@ class Engine:
 
     def diag_clock(self, window_us=20000):
         """Shader clock in MHz the device holds right now, measured inside a kernel over `window_us` (fourq_diag_clock): dict with median,
-        min, max over the probe's 16 waves.  Call it with work queued on the engine's stream for longer than the window."""
-        med, lo, hi = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        self._ck(self._lib.fourq_diag_clock(self._ctx, int(window_us), ctypes.byref(med), ctypes.byref(lo), ctypes.byref(hi)))
-        return {"mhz": med.value, "mhz_min": lo.value, "mhz_max": hi.value, "window_us": int(window_us)}
+        min, max over the probe's 16 waves and `under_load` (the engine's stream still had work in flight when the window closed).  Call
+        it with work queued on the engine's stream for longer than the window."""
+        med, lo, hi, busy = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        self._ck(self._lib.fourq_diag_clock(self._ctx, int(window_us), ctypes.byref(med), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(busy)))
+        return {"mhz": med.value, "mhz_min": lo.value, "mhz_max": hi.value, "window_us": int(window_us), "under_load": bool(busy.value)}
+
+    def diag_clock_begin(self):
+        """First stamp of a clock bracket, enqueued on the engine's stream (fourq_diag_clock_begin): the clock reported by diag_clock_end()
+        is that of everything enqueued between this and diag_clock_stop()."""
+        self._ck(self._lib.fourq_diag_clock_begin(self._ctx))
+
+    def diag_clock_stop(self):
+        """Second stamp, enqueued behind the bracketed work (fourq_diag_clock_stop); the host does not wait."""
+        self._ck(self._lib.fourq_diag_clock_stop(self._ctx))
+
+    def diag_clock_end(self):
+        med, lo, hi, win = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._ck(self._lib.fourq_diag_clock_end(self._ctx, ctypes.byref(med), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(win)))
+        return {"mhz": med.value, "mhz_min": lo.value, "mhz_max": hi.value, "window_us": win.value}
 
     def host_stats(self):
         """Transfer statistics of the last host-array call: bytes, chunks, pinned flags; copy milliseconds and GB/s under host_timing(True)."""

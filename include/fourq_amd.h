@@ -70,7 +70,11 @@ extern "C" {
 typedef struct fourq_ctx fourq_ctx;
 
 /* ---- library / context ---------------------------------------------------------------------- */
-int fourq_version(void);                       /* 10000*major + 100*minor + patch */
+/* The ABI this header describes.  Structs that the library fills (fourq_host_stats) and prototypes may grow between versions: a host
+ * compiled against this header must check fourq_version() == FOURQ_ABI_VERSION once at start-up (the Python binding does, fourq_amd/_lib.py)
+ * -- or use the size-carrying forms (fourq_ctx_host_stats_sized), which never write past what the caller's header knew. */
+#define FOURQ_ABI_VERSION 600
+int fourq_version(void);                       /* 10000*major + 100*minor + patch; == FOURQ_ABI_VERSION for a matching library */
 const char *fourq_build_id(void);              /* 16 hex digits: hash of the sources and flags the library was built from */
 const char *fourq_strerror(int code);
 const char *fourq_last_error(const fourq_ctx *ctx);   /* detail of the last FOURQ_ERR_HIP */
@@ -129,7 +133,7 @@ int fourq_host_free(fourq_ctx *ctx, void *ptr);
 /* transfer statistics of the context's last host-pointer batch call */
 typedef struct fourq_host_stats {
     double h2d_ms, d2h_ms;          /* summed durations of the chunk copies (HIP events), measured only while
-                                     * fourq_ctx_set_host_timing(ctx, 1) is in force -- 0 otherwise: the four event records per
+                                     * fourq_ctx_set_host_timing(ctx, 1) is in force -- 0 otherwise: the six event records per
                                      * chunk are not free, so a production call does not make them (also 0 for a call of at
                                      * most 64 KiB: its kernels read and write a pinned host buffer in place, there are no
                                      * device copies at all) */
@@ -142,6 +146,9 @@ typedef struct fourq_host_stats {
                                      * time between chunks (waiting for bytes, launch gaps) */
 } fourq_host_stats;
 int fourq_ctx_host_stats(const fourq_ctx *ctx, fourq_host_stats *out);
+/* The same, writing at most `size` bytes (pass sizeof(fourq_host_stats) of the header the caller was compiled against): safe across
+ * versions in which the struct grew (0.4.0: 48 bytes, 0.5.0 on: 64). */
+int fourq_ctx_host_stats_sized(const fourq_ctx *ctx, void *out, size_t size);
 /* Diagnostic: time the chunk copies of the following host-pointer calls (h2d_ms / d2h_ms above).  OFF by default; bytes, chunk
  * count and the pinned flags are always reported. */
 int fourq_ctx_set_host_timing(fourq_ctx *ctx, int on);
@@ -151,8 +158,18 @@ int fourq_ctx_set_host_timing(fourq_ctx *ctx, int on);
  * median, minimum and maximum over the probe's waves (two per XCD).  Called while the context's stream has work queued for longer than
  * the window (the _dev calls only enqueue) it reports the clock under that load: a time measured on one box times this clock is a cycle
  * count comparable with another box's (devices differ by several percent in the clock they hold under the same kernel).  Synchronous
- * for the window; no product kernel carries a stamp.  mhz_min / mhz_max may be NULL. */
-int fourq_diag_clock(fourq_ctx *ctx, uint32_t window_us, double *mhz_median, double *mhz_min, double *mhz_max);
+ * for the window; no product kernel carries a stamp.  mhz_min / mhz_max / under_load may be NULL.  *under_load = 1 when the context's
+ * stream still had work in flight when the window closed, 0 when it had already drained (or the probe had queued BEHIND it on a shared
+ * hardware queue): the reading is then the clock of an idle chip and must not be used to convert the load's time into cycles. */
+int fourq_diag_clock(fourq_ctx *ctx, uint32_t window_us, double *mhz_median, double *mhz_min, double *mhz_max, int *under_load);
+/* The clock OF a stretch of work, as a bracket: _begin and _stop each enqueue one tiny kernel on the CONTEXT'S stream -- before and behind
+ * whatever the caller enqueues in between (_dev calls), so the host never waits and nothing stays resident beside the work -- whose waves
+ * record their CU's cycle counter and the global 100 MHz counter; _end (implies _stop) waits for the stream, pairs the two launches' stamps
+ * CU by CU (s_memtime is a per-CU counter) and returns the median clock over the CUs, its 5th / 95th percentile as min / max, and the
+ * length of the window in microseconds.  bench.py brackets its timed steps with it; no product kernel carries a stamp. */
+int fourq_diag_clock_begin(fourq_ctx *ctx);
+int fourq_diag_clock_stop(fourq_ctx *ctx);
+int fourq_diag_clock_end(fourq_ctx *ctx, double *mhz_median, double *mhz_min, double *mhz_max, double *window_us);
 
 /* Plain device-memory helpers so that a host program without a HIP binding can use the _dev API. */
 int fourq_dev_alloc(fourq_ctx *ctx, size_t bytes, void **out);

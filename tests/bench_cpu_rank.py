@@ -42,6 +42,16 @@ class OracleEngine:
     def diag_clock(self, window_us):
         return {"mhz": 1000.0, "mhz_min": 1000.0, "mhz_max": 1000.0, "window_us": window_us}     # no shader clock on a CPU: a placeholder
 
+    def diag_clock_begin(self):
+        self._t0, self._t1 = time.perf_counter(), None
+
+    def diag_clock_stop(self):
+        self._t1 = time.perf_counter()
+
+    def diag_clock_end(self):
+        self._t1 = getattr(self, "_t1", None) or time.perf_counter()
+        return {"mhz": 1000.0, "mhz_min": 1000.0, "mhz_max": 1000.0, "window_us": (self._t1 - self._t0) * 1e6}
+
     def close(self):
         pass
 

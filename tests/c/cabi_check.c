@@ -45,11 +45,26 @@ int main(int argc, char **argv) {
     if ((rc = fourq_mul_endo_batch(ctx, scalars, points, (uint64_t *)pin, (size_t)n)) != FOURQ_OK) return fail("fourq_mul_endo_batch (timed)", rc, ctx);
     if ((rc = fourq_ctx_host_stats(ctx, &st)) != FOURQ_OK) return fail("fourq_ctx_host_stats", rc, ctx);
     if (memcmp(pin, want, n * 160) != 0 || (st.d2h_bytes && !(st.h2d_ms > 0.0 && st.d2h_ms > 0.0))) { fprintf(stderr, "timed call differs\n"); return 1; }
-    double mhz = 0, lo = 0, hi = 0;
-    if ((rc = fourq_diag_clock(ctx, 2000, &mhz, &lo, &hi)) != FOURQ_OK) return fail("fourq_diag_clock", rc, ctx);
+    double mhz = 0, lo = 0, hi = 0, win = 0;
+    int busy = -1;
+    if (fourq_version() != FOURQ_ABI_VERSION) { fprintf(stderr, "library %d, header %d\n", fourq_version(), FOURQ_ABI_VERSION); return 1; }
+    if ((rc = fourq_diag_clock(ctx, 2000, &mhz, &lo, &hi, &busy)) != FOURQ_OK) return fail("fourq_diag_clock", rc, ctx);
     if (!(lo > 100.0 && lo <= mhz && mhz <= hi && hi < 3000.0)) { fprintf(stderr, "implausible clock %.0f MHz (%.0f .. %.0f)\n", mhz, lo, hi); return 1; }
-    if (fourq_diag_clock(ctx, 0, &mhz, NULL, NULL) != FOURQ_ERR_INVALID || fourq_diag_clock(NULL, 10, &mhz, NULL, NULL) != FOURQ_ERR_INVALID) {
+    if (busy != 0) { fprintf(stderr, "fourq_diag_clock says the idle stream was under load\n"); return 1; }
+    if (fourq_diag_clock(ctx, 0, &mhz, NULL, NULL, NULL) != FOURQ_ERR_INVALID || fourq_diag_clock(NULL, 10, &mhz, NULL, NULL, NULL) != FOURQ_ERR_INVALID) {
         fprintf(stderr, "fourq_diag_clock accepts bad arguments\n"); return 1; }
+    /* round 6: the bracket form -- two stamp launches on the context's stream around device-resident work, paired per CU */
+    if ((rc = fourq_diag_clock_begin(ctx)) != FOURQ_OK) return fail("fourq_diag_clock_begin", rc, ctx);
+    if (fourq_diag_clock_begin(ctx) != FOURQ_ERR_INVALID) { fprintf(stderr, "a second bracket was accepted\n"); return 1; }
+    if ((rc = fourq_mul_endo_batch(ctx, scalars, points, (uint64_t *)pin, (size_t)n)) != FOURQ_OK || memcmp(pin, want, n * 160) != 0) return fail("fourq_mul_endo_batch inside a bracket", rc, ctx);
+    if ((rc = fourq_diag_clock_stop(ctx)) != FOURQ_OK) return fail("fourq_diag_clock_stop", rc, ctx);
+    if (fourq_diag_clock_stop(ctx) != FOURQ_ERR_INVALID) { fprintf(stderr, "a bracket was stopped twice\n"); return 1; }
+    if ((rc = fourq_diag_clock_end(ctx, &mhz, &lo, &hi, &win)) != FOURQ_OK) return fail("fourq_diag_clock_end", rc, ctx);
+    if (!(lo > 100.0 && lo <= mhz && mhz <= hi && hi < 3000.0 && win > 50.0 && win < 400000.0)) { fprintf(stderr, "implausible bracket clock %.0f MHz (%.0f .. %.0f) over %.0f us\n", mhz, lo, hi, win); return 1; }
+    if (fourq_diag_clock_end(ctx, &mhz, NULL, NULL, NULL) != FOURQ_ERR_INVALID) { fprintf(stderr, "bracket ended twice\n"); return 1; }
+    unsigned char small[48];
+    memset(small, 0xEE, sizeof small);
+    if ((rc = fourq_ctx_host_stats_sized(ctx, small, 40)) != FOURQ_OK || small[40] != 0xEE) { fprintf(stderr, "fourq_ctx_host_stats_sized wrote past the size it was given\n"); return 1; }
     fourq_host_free(ctx, pin);
     fourq_ctx_destroy(ctx);
     printf("cabi_check: %llu elements, MUL_endo and DH_endo bit-exact through the C ABI\n", (unsigned long long)n);

@@ -173,7 +173,7 @@ def test_bench_rank_body_runs_world_2_over_gloo_without_a_gpu(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    argv = ["--gpus", "2", "--batch", "384", "--steps", "2", "--warmup", "1", "--no-configs", "--no-pcie", "--no-alongside", "--no-ct", "--no-cpu-baseline"]
+    argv = ["--gpus", "2", "--batch", "384", "--steps", "2", "--warmup", "1", "--no-configs", "--no-pcie", "--no-alongside", "--no-ct", "--full-json", str(tmp_path / "full.json")]
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
@@ -183,10 +183,14 @@ def test_bench_rank_body_runs_world_2_over_gloo_without_a_gpu(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\\n".join(o[1][-2000:] for o in outs)
     lines0 = [ln for ln in outs[0][0].splitlines() if ln.startswith('{"metric"')]
     assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith('{"metric"')]      # rank 0 alone speaks
+    assert len(lines0[0]) <= 6144 and [ln for ln in outs[0][0].splitlines() if ln.strip()] == lines0      # the driver's reader: one short line, nothing else
     line = json.loads(lines0[0])
+    full = json.loads([ln for ln in outs[0][1].splitlines() if ln.startswith('{"metric"')][-1])                # the full record: rank 0's stderr
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["scaling"] == "weak"
     assert line["config"]["backend"].startswith("gloo")
-    assert line["parity"]["ok"] is True and line["parity"]["all_ranks_ok"] is True and line["parity"]["units"] == 384
-    assert line["gather_ms"] > 0 and line["steps"] == 2
+    assert line["parity_ok"] is True and full["parity"]["ok"] is True and full["parity"]["all_ranks_ok"] is True and full["parity"]["units"] == 384
+    assert line["gather_ms"] > 0 and line["steps"] == 2 and "cpu_baseline" not in line
+    lo, hi = line["cycles_per_unit_ranks"]
+    assert 0 < lo <= hi
     # whole-job value: both ranks' units over the slower rank's time
     assert abs(line["value"] - 2 * 384 * 2 / (line["ms_per_step"] * 2 * 1e-3)) / line["value"] < 0.01

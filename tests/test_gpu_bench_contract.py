@@ -13,19 +13,68 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(*args):
+LINE_MAX_BYTES = 6144         # the driver could not read a 22 KB line; bench.compact_line refuses to print more than this
+
+
+def run_bench(tmp_path, *args):
+    """(the ONE stdout line, the full record bench.py wrote beside it)"""
     # the contract is about the DEFAULT line: routing and selection knobs of the caller's shell do not reach the child
     env = {k: v for k, v in os.environ.items() if not (k.startswith("FOURQ_") and k != "FOURQ_AMD_LIB")}
     env["FOURQ_BENCH_SETTLE_MS"] = "10"
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, env=env, timeout=900)
+    full_path = str(tmp_path / "bench_full.json")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-json", full_path] + list(args), capture_output=True, text=True, env=env, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, "stdout must carry exactly one line: %r" % lines[:3]
-    return json.loads(lines[0])
+    assert len(lines[0]) <= LINE_MAX_BYTES, "the line is %d bytes" % len(lines[0])
+    assert proc.stdout.rstrip("\n").endswith(lines[0])                    # ... and it is the last thing on stdout
+    with open(full_path) as fh:
+        full = json.load(fh)
+    assert json.loads([ln for ln in proc.stderr.splitlines() if ln.startswith('{"metric"')][-1]) == full      # the same record on stderr
+    return json.loads(lines[0]), full
 
 
-def test_default_line_has_the_contract_keys():
-    line = run_bench("--steps", "20", "--warmup", "2")
+def test_the_compact_line_is_what_the_driver_reads(tmp_path):
+    """one line, numbers only, <= 6 KB, with the contract keys, `roofline` and `cpu_baseline` at top level and one flat
+    record per nested config; everything else in the full record."""
+    short, full = run_bench(tmp_path, "--steps", "20", "--warmup", "5")         # the driver's own arguments
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict),
+                     ("cpu_baseline", dict), ("valu_roofline", dict), ("configs", dict), ("pcie", dict), ("clock_mhz", float), ("cycles_per_unit", float),
+                     ("ct_value", float), ("ct_ratio", float), ("parity_ok", bool)):
+        assert isinstance(short[key], typ), key
+    assert short["vs_baseline"] is None and short["steps"] == 20 and short["warmup"] == 5 and short["parity_ok"] is True
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert short[k] == full[k], k
+    assert set(short["config"]) == {"workload", "batch_per_gpu", "ranks_seen", "backend", "build_id", "built_from_sources", "table_selection"}
+    assert len(short["config"]["workload"]) <= 120 and "configs[1]" in short["config"]["workload"]
+    assert set(short["roofline"]) == {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch"}
+    assert short["roofline"] == {k: full["roofline"][k] for k in short["roofline"]} and len(short["roofline"]["kernel"]) < 40
+    c = short["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] <= c["cores_cap"] and c["cores"] <= c["host_cores_granted"] <= c["host_cores_total"]
+    assert c["per_core_reference_survey"] == 410.0 and c["c_restatement_value"] > c["value"] > 0 and abs(c["per_core"] * c["cores"] - c["value"]) / c["value"] < 0.25
+    assert set(short["configs"]) == {"cfg3", "cfg4", "cfg5"}
+    for name, rec in short["configs"].items():
+        assert len(json.dumps(rec, separators=(",", ":"))) <= 300, name
+        assert rec["parity_ok"] is True and rec["value"] == full["configs"][name]["value"]
+        assert rec["issue_frac"] is None or 0 < rec["issue_frac"] <= 1.05          # None until the PMC profile of THIS build is committed
+        assert rec["pcie_value"] > 0 and 0.95 < rec["ct_ratio"] < 3.0 and 5 < rec["cycles_per_unit"] < 40
+    assert short["ct_value"] == full["ct_select"]["cfg2"]["value"] and short["ct_ratio"] == full["ct_select"]["cfg2"]["ratio_vs_default"]
+    p = short["pcie"]
+    assert 0 < p["r1_2p20_ms"] and 0 < p["affine_2p20_ms"] and 0 < p["bytes_2p20_ms"] and p["ms"] > 0
+    # no prose: every string of the line is a short label
+    def strings(x):
+        if isinstance(x, dict):
+            for v in x.values():
+                yield from strings(v)
+        elif isinstance(x, str):
+            yield x
+    assert max(len(t) for t in strings(short)) <= 160
+    assert short["fields"] == "profiles/BENCH_FIELDS.md" and os.path.exists(os.path.join(ROOT, short["fields"]))
+
+
+def test_default_line_has_the_contract_keys(tmp_path):
+    _, line = run_bench(tmp_path, "--steps", "20", "--warmup", "2")
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict), ("valu_roofline", dict), ("parity", dict),
@@ -62,18 +111,19 @@ def test_default_line_has_the_contract_keys():
     assert v4["algorithmic_mads_per_unit_of_the_algorithm_run"] < v4["algorithmic_mads_per_unit"]
     assert v4["algorithmic_frac_of_the_algorithm_run"] < v4["algorithmic_frac"]
     lib = line["config"]["library"]
-    assert lib["version"] == 500 and len(lib["build_id"]) == 16
+    assert lib["version"] == 600 and len(lib["build_id"]) == 16
     from fourq_amd import build
     assert lib["build_id"] == build.source_id() and lib["built_from_these_sources"] is True         # what was timed is what the sources say
     src = r["traffic_source"]
     assert src["loaded_library_build_id"] == lib["build_id"]
     assert (r["traffic"] is None) == (src.get("profiled_library_build_id") != lib["build_id"])      # a figure only for the build it was measured on
-    assert "masked select" in line["config"]["table_selection"]
+    assert line["config"]["table_selection"] == "indexed"
     # round 5: every workload record carries the in-kernel clock it was measured at and its cost in cycles (comparable across boxes)
     for name, rec in [("cfg2", line)] + sorted(line["configs"].items()):
         clk = rec["clock"]
         cpu = rec["cycles_per_unit"]
         assert 1200 < clk["min_mhz"] <= clk["in_kernel_mhz"] <= clk["max_mhz"] < 2600, (name, clk)
+        assert clk["mode"] == "bracket" and clk["valid"] is True and 0.97 < clk["window_over_timed_span"] < 1.05, (name, clk)    # round 6: the probe's window IS the timed region
         ms = rec["roofline"]["kernel_ms"]
         n_units = rec["config"]["batch_per_gpu"] if name == "cfg2" else rec["batch_per_gpu"]
         assert abs(cpu - ms * 1e-3 * clk["in_kernel_mhz"] * 1e6 / n_units) / cpu < 1e-3, name
@@ -85,13 +135,14 @@ def test_default_line_has_the_contract_keys():
     assert sb["keygen: comb of [392]G == DH_endo(m, G)"]["1"] < 0.6 * sb["DH_endo(m, Q)"]["1"] < sb["MUL_windowed(m, P)"]["1"]
     assert sb["MUL_endo mixed 50/50"]["1024"] < 0.8 * sw["65536"] and sb["MUL_endo(m, G, table) fixed base"]["1"] < sw["1"]
     ct = line["ct_select"]                                         # the constant-time mode, driver-visible: same outputs, its price
-    assert set(ct) == {"cfg2", "cfg3", "cfg4", "cfg5", "mode"}
+    assert set(ct) == {"cfg2", "cfg3", "cfg4", "cfg5"}
     for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
         assert ct[name]["parity_ok"] is True and 0.95 < ct[name]["ratio_vs_default"] < 3.0, name
 
 
-def test_single_workload_line():
-    line = run_bench("--workload", "cfg5", "--steps", "10", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--no-pcie", "--no-ct")
+def test_single_workload_line(tmp_path):
+    short, line = run_bench(tmp_path, "--workload", "cfg5", "--steps", "10", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--no-pcie", "--no-ct")
     assert "configs[4]" in line["config"]["workload"] and "configs" not in line and "cpu_baseline" not in line and "alongside" not in line
     assert "ct_select" not in line and "pcie_inclusive" not in line
     assert line["parity"]["ok"] is True and line["config"]["batch_per_gpu"] == 1 << 17
+    assert "configs" not in short and "cpu_baseline" not in short and "pcie" not in short and short["parity_ok"] is True and "configs[4]" in short["config"]["workload"]

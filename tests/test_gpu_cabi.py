@@ -89,6 +89,7 @@ def test_clock_probe_reads_a_plausible_shader_clock_idle_and_under_load():
     with Engine(0) as e:
         idle = e.diag_clock(2000)
         assert 100 < idle["mhz_min"] <= idle["mhz"] <= idle["mhz_max"] < 2600, idle
+        assert idle["under_load"] is False                      # an idle stream must not pass for a loaded one
         n = e.lanes
         te = e.table_endo(g1)
         s_h = seeded_scalars(8101, n)
@@ -98,7 +99,28 @@ def test_clock_probe_reads_a_plausible_shader_clock_idle_and_under_load():
         for _ in range(300):                                    # ~90 ms of work queued: the probe's 20 ms window lies inside it
             e.mul_endo_dev(s, p, out, n)
         busy = e.diag_clock(20000)
+        assert busy["under_load"] is True
         e.sync()
         assert 1500 < busy["mhz_min"] <= busy["mhz"] <= busy["mhz_max"] < 2600, busy
         assert busy["mhz_max"] - busy["mhz_min"] < 200, busy     # the sixteen probes (two per XCD) agree
         assert np.array_equal(out.cpu().numpy().view(np.uint64), oc.mul(oc.ENDO, s_h, p_h))
+        # round 6: the bracket form -- two stamp launches on the engine's stream around the work, paired per CU; its window is the work's span
+        for _ in range(50):
+            e.mul_endo_dev(s, p, out, n)
+        e.sync()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.Stream(device=dev)
+        e.set_stream(stream)
+        e.diag_clock_begin()
+        ev0.record(stream)
+        for _ in range(100):
+            e.mul_endo_dev(s, p, out, n)
+        ev1.record(stream)
+        e.diag_clock_stop()
+        br = e.diag_clock_end()
+        span_us = ev0.elapsed_time(ev1) * 1e3
+        assert 1500 < br["mhz_min"] <= br["mhz"] <= br["mhz_max"] < 2600 and br["mhz_max"] - br["mhz_min"] < 250, br
+        assert abs(br["window_us"] - span_us) < 0.02 * span_us + 100, (br, span_us)
+        assert abs(br["mhz"] - busy["mhz"]) < 0.06 * busy["mhz"], (br, busy)           # the two forms agree on the clock under the same load
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), oc.mul(oc.ENDO, s_h, p_h))
+        e.set_stream(None)

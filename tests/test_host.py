@@ -161,7 +161,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
         n_args = 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
         assert len(_lib.PROTOTYPES[name][1]) == n_args, name
-    assert lib.fourq_version() == _lib.ABI_VERSION == 500
+    assert lib.fourq_version() == _lib.ABI_VERSION == 600
     assert lib.fourq_strerror(-2).decode() == "no usable gfx950 HIP device"
     # enum values used from Python agree with the header
     for key, val in re.findall(r"FOURQ_(\w+)\s*=\s*(\d+)", header):
