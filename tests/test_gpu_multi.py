@@ -110,12 +110,16 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines[:3]
+    assert len(lines[0]) <= 6144
     line = json.loads(lines[0])
+    full = json.loads([ln for ln in proc.stderr.splitlines() if ln.startswith('{"metric"')][-1])        # rank 0's full record, passed through on stderr
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and "gloo" in line["config"]["backend"]
-    assert line["parity"]["ok"] is True and line["parity"]["all_ranks_ok"] is True and line["parity"]["units"] == 1 << 16
-    assert line["gather_ms"] > 0 and line["scaling"] == "weak"
+    assert line["parity_ok"] is True and full["parity"]["ok"] is True and full["parity"]["all_ranks_ok"] is True and full["parity"]["units"] == 1 << 16
+    assert line["gather_ms"] > 0 and line["scaling"] == "weak" and "cpu_baseline" not in line
     assert abs(line["value"] - 2 * (1 << 16) / (line["ms_per_step"] * 1e-3)) / line["value"] < 0.01     # whole-job units / max-over-ranks time
-    assert line["parity"]["c_oracle_threads"] >= 1                                                      # each rank took a share of the cores
+    assert full["parity"]["c_oracle_threads"] >= 1                                                      # each rank took a share of the cores
+    lo, hi = line["cycles_per_unit_ranks"]                                                              # two ranks time-sharing one GPU: about twice a lone rank's
+    assert 8.0 < lo <= hi < 40.0
 
 
 def test_one_context_called_from_several_threads():
