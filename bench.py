@@ -653,7 +653,7 @@ class Bench:
         times.sort()
         return times[len(times) // 2], times[0], got
 
-    def pcie_inclusive(self, workload, d, want_words, reps):
+    def pcie_inclusive(self, workload, d, want_words, reps, ct_ms=None):
         """SURVEY.md 8(d) wall-clock metric: first H2D byte to last D2H byte through the host-array ABI, from
         host-resident inputs in pinned memory (fourq_host_alloc); the pageable-caller rate beside it.  Outputs are
         compared with the C oracle's."""
@@ -765,8 +765,22 @@ class Bench:
                 dt, best, got = self.timed_calls(call, reps_big)
                 if not all(np.array_equal(got[k * n:(k + 1) * n], want_v) for k in range(16)):
                     raise SystemExit("PARITY FAILURE: host-array path (cfg2 x 16, %s I/O) differs from the C oracle" % label)
-                rec["at_2^20"][label] = {"value": round(big / dt, 1), "ms_per_step": round(dt * 1e3, 3), "best_ms": round(best * 1e3, 3), "chunks": eng.host_stats()["chunks"],
-                                         "wall_gbs_both_directions": round(big * nbytes / dt / 1e9, 2)}
+                hs = eng.host_stats()
+                rec["at_2^20"][label] = {"value": round(big / dt, 1), "ms_per_step": round(dt * 1e3, 3), "best_ms": round(best * 1e3, 3), "chunks": hs["chunks"],
+                                         "wall_gbs_both_directions": round(big * nbytes / dt / 1e9, 2),
+                                         "planned_kernel_ns_per_elem": round(hs["planned_kernel_ns_per_elem"], 3), "planned_from_measurement": bool(hs["planned_from_measurement"])}
+            # The same raw-R1 call on the constant-time context: its chunks are planned with ITS kernels' measured time.
+            # floor = the constant-time kernels device-resident for 2^20 + one generation's copy in + copy out at the link's measured rates.
+            eng_ct = getattr(self, "eng_ct", None)
+            if eng_ct is not None and ct_ms:
+                dt, best, got = self.timed_calls(lambda: eng_ct.mul_endo(sb, pb, out=ob), reps_big)
+                if not all(np.array_equal(got[k * n:(k + 1) * n], want_words) for k in range(16)):
+                    raise SystemExit("PARITY FAILURE: host-array path (cfg2 x 16, raw R1, constant-time context) differs from the C oracle")
+                hs = eng_ct.host_stats()
+                floor = 16 * ct_ms + n * 192 / (rec["gbs_h2d"] * 1e6) + n * 160 / (rec["gbs_d2h"] * 1e6)
+                rec["at_2^20"]["ct_r1"] = {"value": round(big / dt, 1), "ms_per_step": round(dt * 1e3, 3), "best_ms": round(best * 1e3, 3), "chunks": hs["chunks"],
+                                           "floor_ms": round(floor, 3), "over_floor": round(dt * 1e3 / floor, 3),
+                                           "planned_kernel_ns_per_elem": round(hs["planned_kernel_ns_per_elem"], 3), "planned_from_measurement": bool(hs["planned_from_measurement"])}
         for a in pins:
             eng.host_free(a)
         return rec
@@ -1083,7 +1097,7 @@ def main():
         if configs:
             full["configs"] = configs
         if world == 1 and not args.no_pcie and want is not None:
-            full["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=pcie_reps[args.workload])
+            full["pcie_inclusive"] = b.pcie_inclusive(args.workload, d, want, reps=pcie_reps[args.workload], ct_ms=(ct.get(args.workload) or {}).get("ms_per_step"))
         if world == 1 and args.workload == "cfg2" and not args.batch and not args.no_alongside:
             full["size_sweep"] = b.size_sweep(d)
             if not args.no_parity:

@@ -30,7 +30,9 @@ BYTES_DECODE_BASE = 16
 class HostStats(ctypes.Structure):
     """struct fourq_host_stats"""
     _fields_ = [("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double), ("h2d_bytes", c_uint64), ("d2h_bytes", c_uint64),
-                ("chunks", ctypes.c_uint32), ("pinned_in", c_int), ("pinned_out", c_int), ("kernels_ms", ctypes.c_double), ("kernels_span_ms", ctypes.c_double)]
+                ("chunks", ctypes.c_uint32), ("pinned_in", c_int), ("pinned_out", c_int), ("kernels_ms", ctypes.c_double), ("kernels_span_ms", ctypes.c_double),
+                ("planned_kernel_ns_per_elem", ctypes.c_double), ("planned_link_in_gbs", ctypes.c_double), ("planned_link_out_gbs", ctypes.c_double),
+                ("measured_kernel_ns_per_elem", ctypes.c_double), ("planned_from_measurement", c_int)]
 
 
 u64p = POINTER(c_uint64)
@@ -55,6 +57,7 @@ PROTOTYPES = {
     "fourq_host_free": (c_int, [c_void_p, c_void_p]),
     "fourq_ctx_host_stats": (c_int, [c_void_p, c_void_p]),
     "fourq_ctx_host_stats_sized": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "fourq_ctx_host_chunk_stamps": (c_int, [c_void_p, ctypes.c_uint32, POINTER(ctypes.c_double)]),
     "fourq_ctx_set_host_timing": (c_int, [c_void_p, c_int]),
     "fourq_diag_clock": (c_int, [c_void_p, ctypes.c_uint32, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
     "fourq_diag_clock_begin": (c_int, [c_void_p]),

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BLOCK) void lift_affine_kernel(const u64* affine, u
 // way), K = 4 beyond (throughput: 0.29 -> 0.12 ms per 2^20 elements).  ENC: the result leaves as a 32-byte encoding + status byte
 // (curve4q.py:41-47; 16 + decode status where the input did not decode) instead of 64 bytes of affine words.
 template <int K, bool ENC>
-__global__ __launch_bounds__(BLOCK) void lower_kernel(const u64* r1, const uint8_t* st_decode, u64* out, uint8_t* status, u32 n) {
+__global__ __launch_bounds__(BLOCK) void lower_kernel(const u64* r1, u32 stride, const uint8_t* st_decode, u64* out, uint8_t* status, u32 n) {   // stride: 20 (R1 rows) or 12 ((X, Y, Z) rows)
     const u32 T = (n + K - 1) / K;
     const u32 t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= T) return;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void lower_kernel(const u64* r1, const uint8
 #pragma clang loop unroll(full)
     for (int j = 0; j < K; j++) {
         const u32 id = t + (u32)j * T, at = id < n ? id : t;
-        z[j] = load_fe2(r1 + 20 * (size_t)at + 8);
+        z[j] = load_fe2(r1 + stride * (size_t)at + 8);
     }
     Fe<1> one;
     one.l[0] = 1; one.l[1] = one.l[2] = one.l[3] = one.l[4] = 0;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(BLOCK) void lower_kernel(const u64* r1, const uint8
 #pragma clang loop unroll(full)
     for (int j = K - 1; j >= 0; j--) {
         const u32 id = t + (u32)j * T, at = id < n ? id : t;
-        const Fe2<1> X = load_fe2(r1 + 20 * (size_t)at), Y = load_fe2(r1 + 20 * (size_t)at + 4);
+        const Fe2<1> X = load_fe2(r1 + stride * (size_t)at), Y = load_fe2(r1 + stride * (size_t)at + 4);
         Fe<1> ninv = inv;                                              // 1 / |Z_j|^2
         if (j > 0) { ninv = fe_mul(inv, pre[j - 1]); inv = fe_mul(inv, nz[j]); }
         Fe2<1> zi;
@@ -494,8 +494,18 @@ struct fourq_ctx {
     std::vector<hipEvent_t> ticks;     // timing events around the copies, four per chunk of the call: recorded only under host_timing
     int pipe_slots = 0;            // FOURQ_PIPE_SLOTS (test hook): slots in flight, 2..PIPE_SLOTS_MAX; 0 = 4 when the GPU hands slots on, 3 when the host does
     int pipe_gens = 0;             // FOURQ_PIPE_GENS (test hook): > 0 = that many kernel generations per inner chunk instead of the planned sizes (pipeline_plan.h)
+    bool pipe_host_poll = false;   // FOURQ_PIPE_HOST_POLL=1 (test hook): the host's wait for a slot spins on hipEventQuery instead of hipEventSynchronize
     bool pipe_host_wait = false;   // FOURQ_PIPE_HOST_WAIT=1 (test hook): the host waits for a slot's last use before refilling it, as rounds 2-4 did
     bool host_timing = false;      // fourq_ctx_set_host_timing: time the chunk copies with HIP events (h2d_ms / d2h_ms of fourq_host_stats)
+    // Measured planner inputs (round 6): every multi-chunk host-array call times ONE middle chunk (six events, `probe_ticks`) and leaves the
+    // kernel time per element of its route -- per selection mode -- and the link's rate each way here; the next call of that route is planned
+    // with them.  0 = not measured yet: the first call plans with the KT_* guesses (x KT_CT_GUESS in constant-time mode) and 48 GB/s.
+    double plan_kt[32][2] = {};
+    double plan_link_in = 0, plan_link_out = 0;     // bytes per nanosecond
+    hipEvent_t probe_ticks[6] = {};
+    bool fused_io = true;          // FOURQ_FUSED_IO=0 (test hook): the affine / encoded flavours of MUL_* always through lift + full R1 rows, as round 5
+    int plan_measure = 1;          // FOURQ_PIPE_MEASURE=0 (test hook): plan with the compiled-in guesses only, as round 5 did
+    std::vector<float> chunk_stamps;   // under host_timing: six stamps per chunk of the last call, ms since its first event (fourq_ctx_host_chunk_stamps)
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
     u64* diag_stamps = nullptr;    // fourq_diag_clock: 2 x 16 stamps, allocated at its first call
@@ -720,13 +730,17 @@ int stage_table(fourq_ctx* c, const uint64_t* table_host) {
 }
 
 int mul_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points, const uint64_t* table, uint64_t* out,
-            const u32* index, size_t n) {
+            const u32* index, size_t n, u32 io = 0) {
     if (!c || !scalars || !out || (!points && !table) || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(out) || !aligned16(points)) return FOURQ_ERR_INVALID;
     if (n == 0) return FOURQ_OK;
     CtxGuard g(c);
     LadderArgs a = {};
     a.scalars = scalars; a.points = points; a.out = out; a.index = index; a.n = (u32)n;
+    if (io) {                                       // only the fused one-lane kernels read LadderArgs::io: the caller has checked the route (fused_io)
+        if (!points || index || variable_route(c, algo, false, n, false) != ROUTE_FUSED) return FOURQ_ERR_INVALID;
+        a.io = io;
+    }
     if (points) return algo == ENDO ? launch_variable<ENDO, false>(c, a) : launch_variable<WINDOWED, false>(c, a);
     int rc = stage_table(c, table);
     if (rc) return rc;
@@ -848,15 +862,21 @@ int ensure_ticks(fourq_ctx* c, size_t count) {
 
 using ChunkLaunch = std::function<int(char* const* in_dev, char* const* out_dev, size_t m)>;
 
-int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch, size_t chunk_bounce);
+// Which call this is, for the measured planner inputs, and the guess of its kernel time per element for the context's first call of it
+enum PipeRouteId { PR_MUL_VAR = 0, PR_MUL_FIX = 2, PR_DH_VAR = 4, PR_DH_FIX = 6, PR_MIXED = 8, PR_COMB = 9, PR_ENCODE = 10, PR_DECODE = 11, PR_DHB_VAR = 12,
+                   PR_DHB_FIX = 14, PR_AFF = 16, PR_BYTES = 18, PR_EXCH = 20, PR_EXCH_COMB = 22, PR_COUNT = 23 };       // + algo (0 / 1) where two follow each other
+struct PipeRoute { int id; double kt_guess; };
+constexpr double KT_CT_GUESS = 1.3;                 // constant-time selection: x 1.07 - 1.5 by route until the context has measured it
+using PipeReserve = std::function<int(size_t big)>; // sizes the context's intermediates for the largest chunk BEFORE the first chunk is enqueued
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, PipeRoute route, const ChunkLaunch& launch, size_t chunk_bounce, const PipeReserve& reserve);
 // `chunk`: elements of one kernel generation of the route the call takes; `ns_per_elem`: that route's kernel time per element (the
 // KT_* constants below: what sizes the chunks is the ratio of kernel time to copy time, pipeline_plan.h).  `chunk_bounce` (0 = `chunk`):
 // the uniform chunk of a call from PAGEABLE arrays -- its pace is the host's bounce copies (and, where the call allocates its result, the
 // page faults of 160 fresh bytes per element), not the link: such calls keep the chunk shape they were measured with in rounds 2-4
 // (cfg3's call, result array reused: 10.3-10.4 ms at 2^20 then and now; profiles/r02_host_api.txt, profiles/r05_pipeline.txt).
-int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch,
-                 size_t chunk_bounce = 0) {
-    const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, ns_per_elem, launch, chunk_bounce);
+int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, PipeRoute route, const ChunkLaunch& launch,
+                 size_t chunk_bounce = 0, const PipeReserve& reserve = nullptr) {
+    const int rc = run_pipeline_inner(c, in, n_in, out, n_out, n, chunk, route, launch, chunk_bounce, reserve);
     if (rc != FOURQ_OK) {                      // a chunk failed half way: nothing of this call may still be in flight when the caller
         (void)hipStreamSynchronize(c->copy_in);    // gets its buffers (and the context its slots) back
         (void)hipStreamSynchronize(c->stream);
@@ -864,8 +884,8 @@ int run_pipeline(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* o
     }
     return rc;
 }
-int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, double ns_per_elem, const ChunkLaunch& launch, size_t chunk_bounce) {
-    if (n_in > PIPE_MAX_ARRAYS || n_out > PIPE_MAX_ARRAYS || chunk == 0) return FOURQ_ERR_INVALID;
+int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeArray* out, int n_out, size_t n, size_t chunk, PipeRoute route, const ChunkLaunch& launch, size_t chunk_bounce, const PipeReserve& reserve) {
+    if (n_in > PIPE_MAX_ARRAYS || n_out > PIPE_MAX_ARRAYS || chunk == 0 || route.id < 0 || route.id >= 32) return FOURQ_ERR_INVALID;
     bool is_pin_in[PIPE_MAX_ARRAYS], is_pin_out[PIPE_MAX_ARRAYS], any_pageable = false;
     for (int i = 0; i < n_in; i++) { is_pin_in[i] = is_pinned(in[i].src); any_pageable |= !is_pin_in[i]; }
     for (int i = 0; i < n_out; i++) { is_pin_out[i] = is_pinned(out[i].dst); any_pageable |= !is_pin_out[i]; }
@@ -958,10 +978,22 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     for (int i = 0; i < n_out; i++) bytes_out += out[i].stride;
     using fq_plan::Piece;
     std::vector<Piece> plan;
-    try { plan = fq_plan::plan_pieces(n, chunk, bytes_in, bytes_out, ns_per_elem, (bounce && !c->pipe_gens) ? 1 : c->pipe_gens); } catch (...) { return FOURQ_ERR_NOMEM; }
+    // what the plan is priced with: this context's own measurements of this route in this selection mode, or the first call's guesses
+    const int mode = c->ct ? 1 : 0;
+    fq_plan::Rates rates;
+    const bool measured = c->plan_measure && c->plan_kt[route.id][mode] > 0;
+    rates.ns_per_elem = measured ? c->plan_kt[route.id][mode] : route.kt_guess * (c->ct ? KT_CT_GUESS : 1.0);
+    rates.link_in = c->plan_measure && c->plan_link_in > 0 ? c->plan_link_in : fq_plan::LINK_BYTES_PER_NS;
+    rates.link_out = c->plan_measure && c->plan_link_out > 0 ? c->plan_link_out : fq_plan::LINK_BYTES_PER_NS;
+    st.planned_kernel_ns_per_elem = rates.ns_per_elem; st.planned_link_in_gbs = rates.link_in; st.planned_link_out_gbs = rates.link_out;
+    st.planned_from_measurement = measured ? 1 : 0;
+    try { plan = fq_plan::plan_pieces(n, chunk, bytes_in, bytes_out, rates, (bounce && !c->pipe_gens) ? 1 : c->pipe_gens); } catch (...) { return FOURQ_ERR_NOMEM; }
     const size_t pieces = plan.size();
     size_t big = 0;
     for (const Piece& pc : plan) if (pc.m > big) big = pc.m;
+    // planned chunks grow within a call; the context's intermediates (work, proj) are sized ONCE for the largest, so that no
+    // launch() inside the loop reaches grow() -- which would drain the kernel stream and block the host in mid-pipeline
+    if (reserve) { if (int rrc = reserve(big)) return rrc; }
     if (big != chunk) {                                                 // the slot layout above was made for `chunk` elements: redo it for `big`
         slot = 0;
         for (int i = 0; i < n_in; i++) { off_in[i] = slot; slot += align256(big * in[i].stride); }
@@ -970,9 +1002,14 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     st.chunks = (uint32_t)pieces;
     // who hands a slot on: the GPU when every array is copied directly, the host when it has bounce slots to fill and drain
     const bool host_wait = bounce || c->pipe_host_wait;
-    // slots in flight: four with the GPU's hand-over; three with the host's, where a fourth measured WORSE for raw R1 I/O (6.6 ms against
-    // 5.47 at 2^20, profiles/r05_pipeline.txt: measured on two boxes, cause not established)
-    const int want_slots = c->pipe_slots ? c->pipe_slots : (host_wait ? 3 : 4);
+    // Slots in flight: four -- with the GPU's hand-over, and with the host's when it fills and drains bounce slots anyway (pageable callers:
+    // raw R1 7.28 against 7.78 ms at 2^20 with three, the other formats unchanged, profiles/r06_pipeline.txt).  The host's hand-over on PINNED arrays
+    // (FOURQ_PIPE_HOST_WAIT, a test hook) keeps three: with four or more the copy out of chunk slots + 2 -- the one the host is waiting for
+    // with nothing left to enqueue -- makes almost no progress while the three chunks queued behind it run their kernels and completes only
+    // once they are done (1.66 ms instead of 0.42; per-chunk stamps in the same file; a spinning hipEventQuery instead of the blocking wait
+    // changes nothing), so the slot it frees comes 0.6 ms late.  The device copy out is a blit kernel on this runtime; handing slots on
+    // ON THE GPU never leaves that queue without a successor, and does not show it.
+    const int want_slots = c->pipe_slots ? c->pipe_slots : ((host_wait && !bounce) ? 3 : 4);
     const int slots = pieces < (size_t)want_slots ? (int)pieces : want_slots;
     int rc = grow(c, &c->pipe_dev, &c->pipe_dev_bytes, slot * slots, false);
     if (rc) return rc;
@@ -983,9 +1020,20 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     const size_t timed_pieces = c->host_timing ? (pieces < TIMED_MAX ? pieces : TIMED_MAX) : 0;
     if (timed_pieces && (rc = ensure_ticks(c, TK * timed_pieces))) return rc;
     uint64_t timed_h2d = 0, timed_d2h = 0;
+    // the measured planner inputs: ONE chunk of whole generations from the middle of the call, where both directions of the link are busy
+    const size_t whole_pieces = pieces - ((n % chunk) ? 1 : 0);
+    const size_t probe = (c->plan_measure && whole_pieces >= 1) ? (whole_pieces >= 3 ? whole_pieces / 2 : 0) : (size_t)-1;
+    if (probe != (size_t)-1)
+        for (hipEvent_t& e : c->probe_ticks) if (!e) HIP_TRY(c, hipEventCreate(&e));
     auto drain = [&](size_t k) -> int {          // chunk k has left the device: hand a pageable caller its bytes
         const int b = (int)(k % slots);
-        HIP_TRY(c, hipEventSynchronize(c->out_done[b]));
+        if (c->pipe_host_poll) {                 // FOURQ_PIPE_HOST_POLL=1 (experiment, profiles/r06_pipeline.txt): spin on hipEventQuery instead of blocking
+            hipError_t q;
+            while ((q = hipEventQuery(c->out_done[b])) == hipErrorNotReady) {}
+            HIP_TRY(c, q);
+        } else {
+            HIP_TRY(c, hipEventSynchronize(c->out_done[b]));
+        }
         for (int i = 0; i < n_out; i++)
             if (!pin_out[i]) host_copy(out[i].dst + plan[k].off * out[i].stride, c->pipe_pin + (size_t)b * slot + off_out[i], plan[k].m * out[i].stride);
         return FOURQ_OK;
@@ -1004,7 +1052,8 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             din[i] = dev + off_in[i];
             if (!pin_in[i]) host_copy(pin + off_in[i], in[i].src + off * in[i].stride, m * in[i].stride);
         }
-        const bool timed = k < timed_pieces;
+        const bool timed = k < timed_pieces, probed = k == probe;
+        if (probed) HIP_TRY(c, hipEventRecord(c->probe_ticks[0], c->copy_in));
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k], c->copy_in));
         for (int i = 0; i < n_in; i++) {
             const char* src = pin_in[i] ? in[i].src + off * in[i].stride : pin + off_in[i];
@@ -1013,14 +1062,18 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             if (timed) timed_h2d += m * in[i].stride;
         }
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 1], c->copy_in));
+        if (probed) HIP_TRY(c, hipEventRecord(c->probe_ticks[1], c->copy_in));
         HIP_TRY(c, hipEventRecord(c->in_done[b], c->copy_in));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_done[b], 0));
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 4], c->stream));      // the kernel stream is past its wait: the chunk's bytes are there
+        if (probed) HIP_TRY(c, hipEventRecord(c->probe_ticks[2], c->stream));
         for (int i = 0; i < n_out; i++) dout[i] = dev + off_out[i];
         if ((rc = launch(din, dout, m))) return rc;
+        if (probed) HIP_TRY(c, hipEventRecord(c->probe_ticks[3], c->stream));
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 5], c->stream));
         HIP_TRY(c, hipEventRecord(c->kernels_done[b], c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->copy_out, c->kernels_done[b], 0));
+        if (probed) HIP_TRY(c, hipEventRecord(c->probe_ticks[4], c->copy_out));
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 2], c->copy_out));
         for (int i = 0; i < n_out; i++) {
             char* dst = pin_out[i] ? out[i].dst + off * out[i].stride : pin + off_out[i];
@@ -1029,6 +1082,7 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
             if (timed) timed_d2h += m * out[i].stride;
         }
         if (timed) HIP_TRY(c, hipEventRecord(c->ticks[TK * k + 3], c->copy_out));
+        if (probed) HIP_TRY(c, hipEventRecord(c->probe_ticks[5], c->copy_out));
         HIP_TRY(c, hipEventRecord(c->out_done[b], c->copy_out));
     }
     if (host_wait) {
@@ -1037,7 +1091,27 @@ int run_pipeline_inner(fourq_ctx* c, const PipeArray* in, int n_in, const PipeAr
     }
     HIP_TRY(c, hipStreamSynchronize(c->copy_out));      // in order behind every chunk's copy out, which is behind its kernels and its copy in
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (probe != (size_t)-1) {                          // what the next call of this route will be planned with
+        float t_in = 0, t_k = 0, t_out = 0;
+        HIP_TRY(c, hipEventElapsedTime(&t_in, c->probe_ticks[0], c->probe_ticks[1]));
+        HIP_TRY(c, hipEventElapsedTime(&t_k, c->probe_ticks[2], c->probe_ticks[3]));
+        HIP_TRY(c, hipEventElapsedTime(&t_out, c->probe_ticks[4], c->probe_ticks[5]));
+        const double m = (double)plan[probe].m;
+        if (t_k > 0) c->plan_kt[route.id][mode] = (double)t_k * 1e6 / m;
+        // the link's rates only from a chunk that had neighbours on both sides (a call of one or two chunks copies with the link to itself),
+        // and only from a chunk copied directly (a bounce slot's copy is paced by the host threads that fill it)
+        if (whole_pieces >= 3 && !bounce) {
+            if (t_in > 0 && bytes_in) c->plan_link_in = m * (double)bytes_in / ((double)t_in * 1e6);
+            if (t_out > 0 && bytes_out) c->plan_link_out = m * (double)bytes_out / ((double)t_out * 1e6);
+        }
+        st.measured_kernel_ns_per_elem = c->plan_kt[route.id][mode];
+    }
+    try { c->chunk_stamps.clear(); } catch (...) {}
     if (timed_pieces) {
+        try {
+            c->chunk_stamps.resize(TK * timed_pieces);
+            for (size_t i = 0; i < TK * timed_pieces; i++) HIP_TRY(c, hipEventElapsedTime(&c->chunk_stamps[i], c->ticks[0], c->ticks[i]));
+        } catch (...) { c->chunk_stamps.clear(); }
         for (size_t k = 0; k < timed_pieces; k++) {
             float ms = 0;
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ticks[TK * k], c->ticks[TK * k + 1]));
@@ -1077,7 +1151,7 @@ int mul_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* po
     // chunk's copy in and the last chunk's copy out (cfg3's call: 160 B out per element, 21 MB instead of 42 behind the last kernel)
     const size_t unit = points ? pipe_chunk(c, fused) : c->lanes_w4 / 2;
     const double kt = points ? (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) : (algo == ENDO ? KT_ENDO_FIXED : KT_WIN_FIXED);
-    return run_pipeline(c, in, points ? 2 : 1, o, 1, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, points ? 2 : 1, o, 1, n, unit, PipeRoute{ (points ? PR_MUL_VAR : PR_MUL_FIX) + (algo == ENDO ? 0 : 1), kt }, [&](char* const* di, char* const* dout, size_t m) {
         return mul_dev(c, algo, (const uint64_t*)di[0], points ? (const uint64_t*)di[1] : nullptr, table, (uint64_t*)dout[0], nullptr, m);
     }, pipe_chunk(c, fused));
 }
@@ -1091,9 +1165,9 @@ int dh_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poi
     const bool fused = !table && !takes_split_route(c, algo, true, n);
     const size_t unit = table ? c->lanes_w4 / 2 : pipe_chunk(c, fused);
     const double kt = table ? KT_DH_FIXED : (algo == ENDO ? KT_DH_VAR : KT_WIN_VAR + 0.3);
-    return run_pipeline(c, in, 2, o, 2, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 2, n, unit, PipeRoute{ (table ? PR_DH_FIX : PR_DH_VAR) + (algo == ENDO ? 0 : 1), kt }, [&](char* const* di, char* const* dout, size_t m) {
         return dh_dev(c, algo, (const uint64_t*)di[0], (const uint64_t*)di[1], table, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
-    }, pipe_chunk(c, fused));
+    }, pipe_chunk(c, fused), [&](size_t big) { return ensure_proj(c, big); });
 }
 
 int table_host(fourq_ctx* c, int algo, const uint64_t* p_r1, uint64_t* table) {
@@ -1202,6 +1276,9 @@ FQ_API int fourq_ctx_create(int device, fourq_ctx** out) {
         if (const char* env = route_env("FOURQ_PIPE_SLOTS")) { int v = atoi(env); if (v >= 2 && v <= PIPE_SLOTS_MAX) c->pipe_slots = v; }
         if (const char* env = route_env("FOURQ_PIPE_GENS")) { int v = atoi(env); if (v >= 0 && v <= 64) c->pipe_gens = v; }
         if (const char* env = route_env("FOURQ_PIPE_HOST_WAIT")) c->pipe_host_wait = atoi(env) != 0;
+        if (const char* env = route_env("FOURQ_PIPE_HOST_POLL")) c->pipe_host_poll = atoi(env) != 0;
+        if (const char* env = route_env("FOURQ_PIPE_MEASURE")) c->plan_measure = atoi(env) != 0;
+        if (const char* env = route_env("FOURQ_FUSED_IO")) c->fused_io = atoi(env) != 0;
         if (const char* env = getenv("FOURQ_CT_SELECT")) c->ct = atoi(env) != 0;
         if (const char* env = route_env("FOURQ_MIXED_QUEUE")) { int v = atoi(env); if (v == 0 || v == 1) c->mixed_queue = v; }
         c->pair_max = c->lanes / 2;                        // two lanes per element: half a generation fills the chip
@@ -1257,6 +1334,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->diag_bracket) (void)hipFree(c->diag_bracket);
     if (c->shadow_read) (void)hipEventDestroy(c->shadow_read);
     for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->probe_ticks) if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < PIPE_SLOTS_MAX; i++) {
         if (c->in_done[i]) (void)hipEventDestroy(c->in_done[i]);
         if (c->kernels_done[i]) (void)hipEventDestroy(c->kernels_done[i]);
@@ -1454,7 +1532,7 @@ FQ_API int fourq_mul_endo_mixed_batch(fourq_ctx* c, const uint64_t* s, const uin
     // one pass of the work-queue kernel's 4 x CUs waves over 64-element items is `lanes` elements: the unit that lets the copies of a
     // config-5-sized call (2 x lanes) overlap its kernels; raw R1 in and out keeps the chunks at that size (pipeline_plan.h)
     const size_t unit = c->split_chunk < c->lanes ? c->split_chunk : c->lanes;
-    return run_pipeline(c, in, 3, out, 1, n, unit, KT_ENDO_VAR, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 3, out, 1, n, unit, PipeRoute{ PR_MIXED, KT_ENDO_VAR }, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_mul_endo_mixed_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], (const uint8_t*)di[2], table, (uint64_t*)dout[0], m);
     }, c->split_chunk);
 }
@@ -1553,7 +1631,7 @@ FQ_API int fourq_comb_mul_batch(fourq_ctx* c, const uint64_t* scalars, const uin
     comb = nullptr;
     PipeArray in[1] = { { (const char*)scalars, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, KT_COMB, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, PipeRoute{ PR_COMB, KT_COMB }, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_comb_mul_batch_dev(c, (const uint64_t*)di[0], comb, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1580,7 +1658,7 @@ FQ_API int fourq_encode_batch(fourq_ctx* c, const uint64_t* affine, uint8_t* out
     CtxGuard g(c);
     PipeArray in[1] = { { (const char*)affine, nullptr, 64 } };
     PipeArray o[1] = { { nullptr, (char*)out32, 32 } };
-    return run_pipeline(c, in, 1, o, 1, n, 4 * c->lanes_w4, KT_ENCODE, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 1, o, 1, n, 4 * c->lanes_w4, PipeRoute{ PR_ENCODE, KT_ENCODE }, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_encode_batch_dev(c, (const uint64_t*)di[0], (uint8_t*)dout[0], m);
     });
 }
@@ -1590,7 +1668,7 @@ FQ_API int fourq_decode_batch(fourq_ctx* c, const uint8_t* in32, uint64_t* affin
     CtxGuard g(c);
     PipeArray in[1] = { { (const char*)in32, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)affine, 64 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, KT_DECODE, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 1, o, 2, n, c->lanes_w4, PipeRoute{ PR_DECODE, KT_DECODE }, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_decode_batch_dev(c, (const uint8_t*)di[0], (uint64_t*)dout[0], (uint8_t*)dout[1], m);
     });
 }
@@ -1627,28 +1705,32 @@ static int dh_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const 
     const bool fused = !table && !takes_split_route(c, algo, true, n);
     const size_t unit = table ? c->lanes_w4 / 2 : pipe_chunk(c, fused);
     const double kt = (table ? KT_DH_FIXED : (algo == ENDO ? KT_DH_VAR : KT_WIN_VAR + 0.3)) + KT_CODEC;
-    return run_pipeline(c, in, 2, o, 2, n, unit, kt, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 2, n, unit, PipeRoute{ (table ? PR_DHB_FIX : PR_DHB_VAR) + (algo == ENDO ? 0 : 1), kt }, [&](char* const* di, char* const* dout, size_t m) {
         return dh_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], table, (uint8_t*)dout[0], (uint8_t*)dout[1], m);
-    }, pipe_chunk(c, fused));
+    }, pipe_chunk(c, fused), [&](size_t big) { if (int r = ensure_proj(c, big)) return r; return ensure_work(c, dh_bytes_work_bytes(big)); });
 }
 // ---- MUL_* with affine / encoded I/O: R1toAffine(MUL_<algo>(m, AffineToR1(P))) and encode(.) of it --------------------------
 // 160 (96) bytes per operation across the ABI instead of the raw-R1 form's 352: the host-array calls are bound by the link, not by the
 // kernels ("PCIe-inclusive").  Parity level L1 (canonical affine); the raw-R1 entry points are untouched.
 // R1toAffine (+ encode) behind a MUL_*: one inversion per element while the chunk is at most two generations, one per four beyond
-static int launch_lower(fourq_ctx* c, bool enc, const uint64_t* r1, const uint8_t* st_decode, uint64_t* out, uint8_t* status, size_t n) {
+static int launch_lower(fourq_ctx* c, bool enc, const uint64_t* r1, u32 stride, const uint8_t* st_decode, uint64_t* out, uint8_t* status, size_t n) {
     const bool batched = n > 2 * c->lanes;
     const size_t lanes = batched ? (n + 3) / 4 : n;
     const unsigned grid = (unsigned)((lanes + BLOCK - 1) / BLOCK);
     if (enc) {
-        if (batched) hipLaunchKernelGGL((lower_kernel<4, true>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
-        else hipLaunchKernelGGL((lower_kernel<1, true>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
+        if (batched) hipLaunchKernelGGL((lower_kernel<4, true>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, stride, st_decode, out, status, (u32)n);
+        else hipLaunchKernelGGL((lower_kernel<1, true>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, stride, st_decode, out, status, (u32)n);
     } else {
-        if (batched) hipLaunchKernelGGL((lower_kernel<4, false>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
-        else hipLaunchKernelGGL((lower_kernel<1, false>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, st_decode, out, status, (u32)n);
+        if (batched) hipLaunchKernelGGL((lower_kernel<4, false>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, stride, st_decode, out, status, (u32)n);
+        else hipLaunchKernelGGL((lower_kernel<1, false>), dim3(grid), dim3(BLOCK), 0, c->stream, r1, stride, st_decode, out, status, (u32)n);
     }
     HIP_TRY(c, hipGetLastError());
     return FOURQ_OK;
 }
+// Does the whole batch run on the fused one-lane-per-element kernels?  Only those take the affine-in / (X, Y, Z)-out flags (LadderArgs::io):
+// then the lane lifts its own point and leaves the three coordinates R1toAffine reads -- no lift kernel, no R1 rows.  Batches with a
+// two-lane tail or on the two-kernel route keep the separate lift and full R1 rows (FOURQ_FUSED_IO=0, a test hook, forces that everywhere).
+static bool fused_io(const fourq_ctx* c, int algo, size_t n) { return c->fused_io && variable_route(c, algo, false, n, false) == ROUTE_FUSED; }
 static int mul_affine_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points_affine, uint64_t* out_affine, size_t n) {
     if (!c || !scalars || !points_affine || !out_affine || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
     if (!aligned16(scalars) || !aligned16(points_affine) || !aligned16(out_affine)) return FOURQ_ERR_INVALID;
@@ -1658,11 +1740,15 @@ static int mul_affine_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const
     if (rc) return rc;
     uint64_t* r1_in = (uint64_t*)c->work;
     uint64_t* r1_out = (uint64_t*)(c->work + n * 160);
+    if (fused_io(c, algo, n)) {
+        if ((rc = mul_dev(c, algo, scalars, points_affine, nullptr, r1_out, nullptr, n, LADDER_IO_AFFINE_IN | LADDER_IO_XYZ_OUT))) return rc;
+        return launch_lower(c, false, r1_out, 12, nullptr, out_affine, nullptr, n);
+    }
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(lift_affine_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, points_affine, r1_in, (u32)n);
     HIP_TRY(c, hipGetLastError());
     if ((rc = mul_dev(c, algo, scalars, r1_in, nullptr, r1_out, nullptr, n))) return rc;
-    return launch_lower(c, false, r1_out, nullptr, out_affine, nullptr, n);
+    return launch_lower(c, false, r1_out, 20, nullptr, out_affine, nullptr, n);
 }
 static int mul_affine_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* points_affine, uint64_t* out_affine, size_t n) {
     if (!c || !scalars || !points_affine || !out_affine || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
@@ -1670,9 +1756,9 @@ static int mul_affine_host(fourq_ctx* c, int algo, const uint64_t* scalars, cons
     CtxGuard g(c);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points_affine, nullptr, 64 } };
     PipeArray o[1] = { { nullptr, (char*)out_affine, 64 } };
-    return run_pipeline(c, in, 2, o, 1, n, pipe_chunk(c, true), (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) + KT_LIFT_LOWER, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 1, n, pipe_chunk(c, true), PipeRoute{ PR_AFF + (algo == ENDO ? 0 : 1), (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) + KT_LIFT_LOWER }, [&](char* const* di, char* const* dout, size_t m) {
         return mul_affine_dev(c, algo, (const uint64_t*)di[0], (const uint64_t*)di[1], (uint64_t*)dout[0], m);
-    });
+    }, 0, [&](size_t big) { return ensure_work(c, mul_affine_work_bytes(big)); });
 }
 // decode -> MUL_<algo> -> encode.  status: 0 ok | 16 + FOURQ_DECODE_* (out32 is zero then); MUL_* itself cannot fail.
 static int mul_bytes_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint8_t* points32, uint8_t* out32, uint8_t* status, size_t n) {
@@ -1682,14 +1768,20 @@ static int mul_bytes_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const 
     CtxGuard g(c);
     int rc = ensure_work(c, mul_affine_work_bytes(n));
     if (rc) return rc;
-    uint64_t* r1_in = (uint64_t*)c->work;                       // decoded and lifted points
+    uint64_t* r1_in = (uint64_t*)c->work;                       // decoded (and lifted) points
     uint64_t* r1_out = (uint64_t*)(c->work + n * 160);
     uint8_t* st_decode = (uint8_t*)(c->work + 2 * n * 160 + n * 64);
     const unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+    if (fused_io(c, algo, n)) {                                 // decode to affine rows; the ladder's lanes lift them and leave (X, Y, Z)
+        hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, (const u64*)points32, r1_in, st_decode, (u32)n);
+        HIP_TRY(c, hipGetLastError());
+        if ((rc = mul_dev(c, algo, scalars, r1_in, nullptr, r1_out, nullptr, n, LADDER_IO_AFFINE_IN | LADDER_IO_XYZ_OUT))) return rc;
+        return launch_lower(c, true, r1_out, 12, st_decode, (uint64_t*)out32, status, n);
+    }
     hipLaunchKernelGGL(decode_lift_kernel, dim3(grid), dim3(BLOCK), 0, c->stream, (const u64*)points32, r1_in, st_decode, (u32)n);
     HIP_TRY(c, hipGetLastError());
     if ((rc = mul_dev(c, algo, scalars, r1_in, nullptr, r1_out, nullptr, n))) return rc;
-    return launch_lower(c, true, r1_out, st_decode, (uint64_t*)out32, status, n);
+    return launch_lower(c, true, r1_out, 20, st_decode, (uint64_t*)out32, status, n);
 }
 static int mul_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const uint8_t* points32, uint8_t* out32, uint8_t* status, size_t n) {
     if (!c || !scalars || !points32 || !out32 || !status || n > FOURQ_MAX_BATCH) return FOURQ_ERR_INVALID;
@@ -1697,9 +1789,9 @@ static int mul_bytes_host(fourq_ctx* c, int algo, const uint64_t* scalars, const
     CtxGuard g(c);
     PipeArray in[2] = { { (const char*)scalars, nullptr, 32 }, { (const char*)points32, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out32, 32 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, true), (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) + KT_LIFT_LOWER + KT_CODEC, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 2, n, pipe_chunk(c, true), PipeRoute{ PR_BYTES + (algo == ENDO ? 0 : 1), (algo == ENDO ? KT_ENDO_VAR : KT_WIN_VAR) + KT_LIFT_LOWER + KT_CODEC }, [&](char* const* di, char* const* dout, size_t m) {
         return mul_bytes_dev(c, algo, (const uint64_t*)di[0], (const uint8_t*)di[1], (uint8_t*)dout[0], (uint8_t*)dout[1], m);
-    });
+    }, 0, [&](size_t big) { return ensure_work(c, mul_affine_work_bytes(big)); });
 }
 FQ_API int fourq_mul_endo_affine_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) { return mul_affine_dev(c, ENDO, s, p, o, n); }
 FQ_API int fourq_mul_windowed_affine_batch_dev(fourq_ctx* c, const uint64_t* s, const uint64_t* p, uint64_t* o, size_t n) { return mul_affine_dev(c, WINDOWED, s, p, o, n); }
@@ -1756,9 +1848,9 @@ FQ_API int fourq_dh_exchange_batch(fourq_ctx* c, const uint64_t* a, const uint64
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
     // one generation of the fixed-base half (two waves per SIMD) = two of the variable-base half (one wave per SIMD)
-    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, (table392 ? KT_DH_FIXED : KT_DH_VAR) + KT_DH_VAR, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, PipeRoute{ PR_EXCH + (table392 ? 1 : 0), (table392 ? KT_DH_FIXED : KT_DH_VAR) + KT_DH_VAR }, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_dh_exchange_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], base_copy, table392, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
-    }, c->lanes_w4);
+    }, c->lanes_w4, [&](size_t big) { if (int r = ensure_proj(c, big)) return r; return ensure_work(c, exchange_work_bytes(big)); });
 }
 
 // dh_exchange with the key-generation half through the comb (bench.py's cfg4 step as one call)
@@ -1784,9 +1876,9 @@ FQ_API int fourq_dh_exchange_comb_batch(fourq_ctx* c, const uint64_t* a, const u
     if (int rc = stage_comb(c, comb)) return rc;                            // compared once, not once per chunk
     PipeArray in[2] = { { (const char*)a, nullptr, 32 }, { (const char*)b, nullptr, 32 } };
     PipeArray o[2] = { { nullptr, (char*)out, 64 }, { nullptr, (char*)status, 1 } };
-    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, KT_COMB + KT_DH_VAR, [&](char* const* di, char* const* dout, size_t m) {
+    return run_pipeline(c, in, 2, o, 2, n, c->lanes_w4 / 2, PipeRoute{ PR_EXCH_COMB, KT_COMB + KT_DH_VAR }, [&](char* const* di, char* const* dout, size_t m) {
         return fourq_dh_exchange_comb_batch_dev(c, (const uint64_t*)di[0], (const uint64_t*)di[1], nullptr, (uint64_t*)dout[0], (uint8_t*)dout[1], m);
-    }, c->lanes_w4);
+    }, c->lanes_w4, [&](size_t big) { if (int r = ensure_proj(c, big)) return r; return ensure_work(c, exchange_work_bytes(big)); });
 }
 
 // ---- pinned host memory and transfer statistics of the host-pointer calls ---------------------------------------
@@ -1922,6 +2014,14 @@ FQ_API int fourq_ctx_host_stats(const fourq_ctx* c, fourq_host_stats* out) {
     return FOURQ_OK;
 }
 
+FQ_API int fourq_ctx_host_chunk_stamps(const fourq_ctx* c, uint32_t chunk, double out_ms[6]) {
+    if (!c || !out_ms) return FOURQ_ERR_INVALID;
+    std::unique_lock<std::recursive_mutex> lock(c->mu);
+    if ((size_t)chunk * 6 + 6 > c->chunk_stamps.size()) return FOURQ_ERR_INVALID;
+    // event order in the pipeline: copy-in start, copy-in end, copy-out start, copy-out end, kernels start, kernels end
+    for (int i = 0; i < 6; i++) out_ms[i] = c->chunk_stamps[(size_t)chunk * 6 + i];
+    return FOURQ_OK;
+}
 FQ_API int fourq_ctx_host_stats_sized(const fourq_ctx* c, void* out, size_t size) {
     if (!c || !out) return FOURQ_ERR_INVALID;
     memcpy(out, &c->host_stats, size < sizeof c->host_stats ? size : sizeof c->host_stats);

@@ -119,7 +119,12 @@ struct LadderArgs {
                            // there for normalize_kernel (always the case on the PREBUILT route)
     u32 proj_stride;       // elements per plane
     u32 n;
+    u32 io;                // fused MUL_* kernels (one lane per element) only -- LADDER_IO_AFFINE_IN: `points` is n x 8 affine words and the lane lifts
+                           // it itself (curve4q.py:100-101); LADDER_IO_XYZ_OUT: `out` is n x 12 words, (X, Y, Z) of the result only (what
+                           // R1toAffine reads, curve4q.py:103-106).  Wave-uniform branches in front of and behind the ladder: the affine / encoded
+                           // I/O flavours of MUL_* need no lift kernel and no 160-byte R1 rows on either side (round 6)
 };
+constexpr u32 LADDER_IO_AFFINE_IN = 1, LADDER_IO_XYZ_OUT = 2;
 
 // ---- small helpers -----------------------------------------------------------------------------
 FQ_DEV void store_xyz(u32* dst, const Fe2<1>& X, const Fe2<1>& Y, const Fe2<1>& Z) {
@@ -617,7 +622,8 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
                 if (!point_on_curve(x, y)) st = FOURQ_DH_NOT_ON_CURVE;  // keep going branch-free; masked at the end
                 if (SRC == FUSED) P = clear_cofactor_392(x, y);         // with a table the reference discards [392]P (curve4q.py:209)
             } else if (SRC == FUSED) {
-                P = load_r1(a.points + 20 * (size_t)id);
+                if (a.io & LADDER_IO_AFFINE_IN) P = affine_to_r1(load_fe2(a.points + 8 * (size_t)id), load_fe2(a.points + 8 * (size_t)id + 4));
+                else P = load_r1(a.points + 20 * (size_t)id);
             }
             if constexpr (SRC == FUSED) {
                 if constexpr (ALGO == ENDO && FQ_TABLE_ASM && FQ_LADDER_ASM) build_table_endo_lds_asm<L>(P, slot, ef);
@@ -683,9 +689,11 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
         } else if (live) {
             u64 o[20];
             store_r1(o, Q);
-            uint4* dst = reinterpret_cast<uint4*>(a.out + 20 * (size_t)id);
+            const bool xyz = SRC == FUSED && (a.io & LADDER_IO_XYZ_OUT);
+            uint4* dst = reinterpret_cast<uint4*>(a.out + (xyz ? 12 : 20) * (size_t)id);
 #pragma unroll
-            for (int k = 0; k < 10; k++) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
+            for (int k = 0; k < 10; k++)
+                if (k < 6 || !xyz) dst[k] = make_uint4((u32)o[2 * k], (u32)(o[2 * k] >> 32), (u32)o[2 * k + 1], (u32)(o[2 * k + 1] >> 32));
         }
     }
 }

@@ -161,6 +161,14 @@ class Engine:
         d["gbs_d2h"] = st.d2h_bytes / st.d2h_ms / 1e6 if st.d2h_ms > 0 else None
         return d
 
+    def host_chunk_stamps(self):
+        """Per chunk of the last host-array call made under host_timing(True): [copy-in start, copy-in end, copy-out start, copy-out end,
+        kernels start, kernels end] in ms since the call's first event (fourq_ctx_host_chunk_stamps)."""
+        rows, buf = [], (ctypes.c_double * 6)()
+        while self._lib.fourq_ctx_host_chunk_stamps(self._ctx, len(rows), buf) == 0:
+            rows.append(list(buf))
+        return rows
+
     def reserve(self, n):
         """Size the context's internal buffers for `*_dev` batches of up to n elements (fourq_ctx_reserve): such calls then
         only enqueue -- no hidden stream synchronisation, capturable into a HIP graph."""

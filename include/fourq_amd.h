@@ -103,7 +103,7 @@ int fourq_ctx_sync(fourq_ctx *ctx);
  * bit-identical in both modes; the price of ON is in DESIGN.md section 10.
  * Environment: FOURQ_CT_SELECT is the ONE variable the library reads as a product option.  The variables that steer batches onto
  * particular kernels (FOURQ_SPLIT_*, FOURQ_PAIR_MAX, FOURQ_QUAD_MAX, FOURQ_MIXED_QUEUE, FOURQ_NORM_K, FOURQ_BLOCKS_PER_CU,
- * FOURQ_HOST_BOUNCE, FOURQ_HOST_ZERO_COPY, FOURQ_PIPE_SLOTS, FOURQ_PIPE_GENS, FOURQ_PIPE_HOST_WAIT) are test hooks: they are ignored unless FOURQ_DEBUG_ROUTES=1 is set (tools/README.md).
+ * FOURQ_HOST_BOUNCE, FOURQ_HOST_ZERO_COPY, FOURQ_PIPE_SLOTS, FOURQ_PIPE_GENS, FOURQ_PIPE_HOST_WAIT, FOURQ_PIPE_HOST_POLL, FOURQ_PIPE_MEASURE, FOURQ_FUSED_IO) are test hooks: they are ignored unless FOURQ_DEBUG_ROUTES=1 is set (tools/README.md).
  * One variable of the HIP RUNTIME matters to the host-pointer calls: they overlap copy-in, kernels and copy-out on three streams,
  * and the runtime shares GPU_MAX_HW_QUEUES hardware queues (default 4) among all streams the process uses -- in a process with two
  * or more other busy streams the three stages take turns and a large call takes up to twice as long.  Set GPU_MAX_HW_QUEUES=8 in
@@ -144,14 +144,25 @@ typedef struct fourq_host_stats {
                                      * bytes" to "the chunk's kernels are done" (HIP events on the kernel stream); 0 otherwise */
     double kernels_span_ms;         /* ... and from the first chunk's start to the last chunk's end: span - sum = the kernel stream's idle
                                      * time between chunks (waiting for bytes, launch gaps) */
+    /* 0.6.0: what the call's chunks were PLANNED with (fourq_amd/csrc/pipeline_plan.h) -- the context's own measurements of this route in this
+     * selection mode when planned_from_measurement is 1 (every multi-chunk call times one middle chunk and leaves the figures for the next
+     * call of the same route), the compiled-in first-call guesses when 0 -- and what THIS call measured.  0 for a call of one chunk. */
+    double planned_kernel_ns_per_elem, planned_link_in_gbs, planned_link_out_gbs;   /* kernel time per element; link rate each way, GB/s = bytes / ns */
+    double measured_kernel_ns_per_elem;
+    int planned_from_measurement;
 } fourq_host_stats;
 int fourq_ctx_host_stats(const fourq_ctx *ctx, fourq_host_stats *out);
 /* The same, writing at most `size` bytes (pass sizeof(fourq_host_stats) of the header the caller was compiled against): safe across
- * versions in which the struct grew (0.4.0: 48 bytes, 0.5.0 on: 64). */
+ * versions in which the struct grew (0.4.0: 48 bytes, 0.5.0: 64, 0.6.0: 104). */
 int fourq_ctx_host_stats_sized(const fourq_ctx *ctx, void *out, size_t size);
 /* Diagnostic: time the chunk copies of the following host-pointer calls (h2d_ms / d2h_ms above).  OFF by default; bytes, chunk
  * count and the pinned flags are always reported. */
 int fourq_ctx_set_host_timing(fourq_ctx *ctx, int on);
+/* Diagnostic: where chunk `chunk` of the context's last host-pointer call sat in time, when that call was made under
+ * fourq_ctx_set_host_timing -- six stamps in milliseconds since the call's first event: copy-in start, copy-in end, copy-out start,
+ * copy-out end, kernels start (the kernel stream is past its wait for the chunk's bytes), kernels end.  FOURQ_ERR_INVALID past the
+ * last timed chunk (tools/pipeline_chunks.py prints the table). */
+int fourq_ctx_host_chunk_stamps(const fourq_ctx *ctx, uint32_t chunk, double out_ms[6]);
 
 /* Diagnostic: the shader clock (MHz) the device holds at this moment, measured from inside a kernel -- a 16-wave probe on a stream of
  * the context's own times `window_us` (1 .. 1 000 000) of the constant 100 MHz counter (s_memrealtime) in shader cycles (s_memtime);

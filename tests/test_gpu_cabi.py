@@ -121,6 +121,8 @@ def test_clock_probe_reads_a_plausible_shader_clock_idle_and_under_load():
         span_us = ev0.elapsed_time(ev1) * 1e3
         assert 1500 < br["mhz_min"] <= br["mhz"] <= br["mhz_max"] < 2600 and br["mhz_max"] - br["mhz_min"] < 250, br
         assert abs(br["window_us"] - span_us) < 0.02 * span_us + 100, (br, span_us)
-        assert abs(br["mhz"] - busy["mhz"]) < 0.06 * busy["mhz"], (br, busy)           # the two forms agree on the clock under the same load
+        # the two forms agree on the clock under the same load -- to within the governor's ramp: the first probe's window was the first 20 ms
+        # after idle (profiles/clock_ramp_r01.txt), the bracket's lies 100 ms into the load
+        assert busy["mhz"] * 0.97 < br["mhz"] < busy["mhz"] * 1.2, (br, busy)
         assert np.array_equal(out.cpu().numpy().view(np.uint64), oc.mul(oc.ENDO, s_h, p_h))
         e.set_stream(None)

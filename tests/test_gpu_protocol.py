@@ -228,7 +228,10 @@ def test_host_pipeline_shapes_slots_handed_on_by_the_gpu(slots, gens, host_wait)
         for rep in range(2):                                       # the second call finds the slots' events already used
             got = e.mul_endo(s_p, p_p, out=o_p)
             st = e.host_stats()
-            assert st["chunks"] == pieces and st["pinned_in"] == 1 and st["pinned_out"] == 1
+            # planned chunks follow the context's own measurements from the second call on (round 6): in constant-time mode the slower kernels
+            # leave room for a two-generation chunk or two
+            assert (st["chunks"] == pieces if gens or rep == 0 else pieces - 2 <= st["chunks"] <= pieces) and st["pinned_in"] == 1 and st["pinned_out"] == 1
+            assert st["planned_from_measurement"] == rep and st["measured_kernel_ns_per_elem"] > 0
             assert np.array_equal(got, want), "pinned, call %d" % rep
             o_p[:] = 0
         assert np.array_equal(e.mul_endo(s_h, p_h), want), "pageable"
@@ -241,6 +244,110 @@ def test_host_pipeline_shapes_slots_handed_on_by_the_gpu(slots, gens, host_wait)
             e.host_free(arr)
     finally:
         e.close()
+
+
+def test_planner_inputs_are_measured_by_the_context_itself():
+    """the chunk planner's inputs are no longer constants of one box and one mode.  A context's first multi-chunk call of a
+    route plans with the compiled-in guess (x 1.3 in constant-time mode); every such call times one middle chunk -- its kernels and its
+    copies, both directions of the link busy -- and the next call of that route on that context is planned with those figures.  A
+    constant-time context therefore plans for ITS kernels; the figures are per route and per selection mode."""
+    from fourq_amd import Engine
+    with Engine(0) as e:
+        lanes = e.lanes
+        n = 8 * lanes
+        te = oc.table(oc.ENDO, codec.pack_point(G1))
+        s_h = seeded_scalars(181, n)
+        p_h = e.mul_endo_fixed(seeded_scalars(182, n), te)
+        s_p, p_p, o_p = e.host_array(s_h), e.host_array(p_h), e.host_empty((n, 20))
+        seen = {}
+        for ct in (False, True):
+            e.ct_select = ct
+            e.mul_endo(s_p, p_p, out=o_p)
+            st = e.host_stats()
+            assert st["planned_from_measurement"] == 0 and abs(st["planned_kernel_ns_per_elem"] - 4.63 * (1.3 if ct else 1.0)) < 1e-9
+            if not ct:
+                assert st["planned_link_in_gbs"] == 48.0 and st["planned_link_out_gbs"] == 48.0          # nothing measured yet
+            first = st["measured_kernel_ns_per_elem"]
+            assert 3.5 < first < 9.0
+            e.mul_endo(s_p, p_p, out=o_p)
+            st = e.host_stats()
+            assert st["planned_from_measurement"] == 1 and st["planned_kernel_ns_per_elem"] == first
+            assert 25.0 < st["planned_link_in_gbs"] < 70.0 and 25.0 < st["planned_link_out_gbs"] < 70.0, st
+            seen[ct] = st["measured_kernel_ns_per_elem"]
+        assert seen[True] > 1.08 * seen[False], seen                     # the constant-time ladder reads the whole table at every step
+        want = oc.mul(oc.ENDO, s_h, p_h)
+        assert np.array_equal(o_p, want)
+        # another route on the same context starts from its own guess again
+        a_p, oa_p = e.host_array(oc.r1_to_affine(p_h)), e.host_empty((n, 8))
+        e.ct_select = False
+        e.mul_affine(s_p, a_p, out=oa_p)
+        st = e.host_stats()
+        assert st["planned_from_measurement"] == 0 and st["planned_link_in_gbs"] != 48.0                 # the link's rates are the context's, not the route's
+        assert np.array_equal(oa_p, oc.r1_to_affine(want))
+        # the per-chunk stamps of a call made under host_timing (fourq_ctx_host_chunk_stamps): one row per chunk, each stage in order
+        e.host_timing(True)
+        e.mul_endo(s_p, p_p, out=o_p)
+        rows = e.host_chunk_stamps()
+        e.host_timing(False)
+        assert len(rows) == e.host_stats()["chunks"]
+        for k, (i0, i1, o0, o1, k0, k1) in enumerate(rows):
+            assert i0 <= i1 <= k0 + 0.05 and k0 < k1 <= o0 + 0.05 and o0 < o1, (k, rows[k])
+        assert all(rows[k][4] >= rows[k - 1][5] - 0.05 for k in range(1, len(rows)))                     # one kernel stream: chunk k's kernels behind chunk k-1's
+        for arr in (s_p, p_p, o_p, a_p, oa_p):
+            e.host_free(arr)
+
+
+def test_fused_io_flags_give_the_three_kernel_route_s_words():
+    """Round 6: on whole fused generations the affine / encoded flavours of MUL_* hand the ladder affine rows and take (X, Y, Z) rows back
+    (LadderArgs::io) -- no lift kernel, no R1 rows.  Same words as round 5's route (FOURQ_FUSED_IO=0, a test hook) and as the C oracle,
+    host arrays (chunks of whole generations + a tail on the two-lane kernels) and one device-resident launch, both ladders, both modes."""
+    import os
+    import torch
+    from fourq_amd import Engine
+    dev = torch.device("cuda", 0)
+    outs = {}
+    for hook in ("1", "0"):
+        saved = {k: os.environ.get(k) for k in ("FOURQ_FUSED_IO", "FOURQ_DEBUG_ROUTES")}
+        os.environ.update(FOURQ_FUSED_IO=hook, FOURQ_DEBUG_ROUTES="1")
+        try:
+            e = Engine(0)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        try:
+            lanes = e.lanes
+            n = 3 * lanes + 77
+            te = oc.table(oc.ENDO, codec.pack_point(G1))
+            s_h = seeded_scalars(191, n)
+            r1_h = e.mul_endo_fixed(seeded_scalars(192, n), te)
+            aff = oc.r1_to_affine(r1_h)
+            enc = oc.encode(aff)
+            enc[5, 15] |= 0x80                                            # one key that does not decode: reserved bit
+            for ct in (False, True):
+                e.ct_select = ct
+                for kind, okind in (("endo", oc.ENDO), ("windowed", oc.WINDOWED)):
+                    got_a = e.mul_affine(s_h, aff, kind=kind)
+                    got_b, st_b = e.mul_bytes(s_h, enc, kind=kind)
+                    m = 2 * lanes                                         # device-resident, whole generations: one launch with the flags
+                    sd, ad = (torch.from_numpy(np.ascontiguousarray(a[:m]).view(np.int64)).to(dev) for a in (s_h, aff))
+                    od = torch.empty((m, 8), dtype=torch.int64, device=dev)
+                    e.mul_affine_dev(sd, ad, od, m, kind=kind)
+                    e.sync()
+                    assert np.array_equal(od.cpu().numpy().view(np.uint64), got_a[:m])
+                    outs[(hook, ct, kind)] = (got_a, got_b, st_b)
+                    if hook == "1":
+                        lifted = np.zeros((n, 20), dtype=np.uint64)
+                        lifted[:, 0:8] = aff; lifted[:, 8] = 1; lifted[:, 12:20] = aff
+                        want = oc.r1_to_affine(oc.mul(okind, s_h, lifted))
+                        assert np.array_equal(got_a, want), (ct, kind)
+                        assert st_b[5] == 16 + 1 and not got_b[5].any() and not np.delete(st_b, 5).any()
+                        assert np.array_equal(np.delete(got_b, 5, axis=0), np.delete(oc.encode(want), 5, axis=0)), (ct, kind)
+        finally:
+            e.close()
+    for ct in (False, True):
+        for kind in ("endo", "windowed"):
+            a, b = outs[("1", ct, kind)], outs[("0", ct, kind)]
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (ct, kind)
 
 
 @pytest.mark.parametrize("pinned", [False, True])

@@ -83,7 +83,7 @@ def test_every_environment_variable_the_library_reads_is_documented():
     readme = open(os.path.join(ROOT, "tools", "README.md")).read()
     hooks = {"FOURQ_BLOCKS_PER_CU", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_PAIR_MAX",
              "FOURQ_QUAD_MAX", "FOURQ_MIXED_QUEUE", "FOURQ_NORM_K", "FOURQ_HOST_BOUNCE", "FOURQ_HOST_ZERO_COPY",
-             "FOURQ_PIPE_SLOTS", "FOURQ_PIPE_GENS", "FOURQ_PIPE_HOST_WAIT"}
+             "FOURQ_PIPE_SLOTS", "FOURQ_PIPE_GENS", "FOURQ_PIPE_HOST_WAIT", "FOURQ_PIPE_HOST_POLL", "FOURQ_PIPE_MEASURE", "FOURQ_FUSED_IO"}
     env_like = {v for v in in_lib if not v.startswith(("FOURQ_ERR", "FOURQ_OK", "FOURQ_DH_", "FOURQ_DECODE", "FOURQ_FP", "FOURQ_PT", "FOURQ_MAX", "FOURQ_TABLE", "FOURQ_COMB_", "FOURQ_R"))}
     assert env_like == hooks | {"FOURQ_CT_SELECT", "FOURQ_DEBUG_ROUTES"}, sorted(env_like ^ (hooks | {"FOURQ_CT_SELECT", "FOURQ_DEBUG_ROUTES"}))
     assert "FOURQ_CT_SELECT" in header and "FOURQ_DEBUG_ROUTES" in header
@@ -176,7 +176,8 @@ def test_abi_exports_every_declared_symbol():
                  "DECODE_OK", "DECODE_RESERVED_BIT", "DECODE_NOT_ON_CURVE", "DECODE_REF_ATTRIBUTE_ERROR"):
         assert value("FOURQ_" + name) == getattr(_lib, name), name
     import ctypes
-    assert ctypes.sizeof(_lib.HostStats) == 64                     # struct fourq_host_stats: 2 doubles, 2 u64, u32 + 2 ints (+ pad), 2 doubles
+    assert ctypes.sizeof(_lib.HostStats) == 104                    # struct fourq_host_stats: 2 doubles, 2 u64, u32 + 2 ints (+ pad), 2 doubles; 0.6.0: 4 doubles, int (+ pad)
+    assert value("FOURQ_ABI_VERSION") == _lib.ABI_VERSION
     iw, ow = ctypes.c_size_t(), ctypes.c_size_t()
     for key, code in _lib.PRIM.items():
         assert lib.fourq_prim_words(code, ctypes.byref(iw), ctypes.byref(ow)) == 0 and iw.value and ow.value, key
