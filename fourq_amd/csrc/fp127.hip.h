@@ -569,6 +569,16 @@ template <int B> FQ_DEV Fe<1> fe_unsign(const Fe<B>& a) {
     for (int i = 0; i < 5; i++) u.l[i] = a.l[i] + bias_limb(B + 1, i);
     return fe_carry(u);
 }
+// the same without the carry: non-negative limbs of bound 2B + 1 -- for a consumer that carries anyway (fe_canon in front of the final
+// store: round 6, one carry chain per field element of the result instead of two)
+template <int B> FQ_DEV Fe<2 * B + 1> fe_unsign_wide(const Fe<B>& a) {
+    static_assert((u64)(B + 1) * (LIMB_MASK - 7) >= (u64)B * UNIT, "bias too small");
+    static_assert((u64)(2 * B + 1) * UNIT + (1ull << 20) < (1ull << 32), "limb overflow");
+    Fe<2 * B + 1> u;
+#pragma unroll
+    for (int i = 0; i < 5; i++) u.l[i] = a.l[i] + bias_limb(B + 1, i);
+    return u;
+}
 template <int B> FQ_DEV Fe2<1> fe2_unsign(const Fe2<B>& a) {
     Fe2<1> r; r.re = fe_unsign(a.re); r.im = fe_unsign(a.im); return r;
 }

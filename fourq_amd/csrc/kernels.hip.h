@@ -352,6 +352,51 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
     }
     return ladder_result<CH>(Q);
 }
+// The fused kernels' ladder on the nibble stream (recode_nibbles) and with the lane's entries addressed as a 32-bit dword offset on the
+// kernel's scratch pointer (`base` is wave-uniform: the loads take it as their scalar base).  Same steps, same bodies, same R1 tuple as
+// ladder_endo<3, true, L, EF>; what changes is the glue between the bodies: per step one bit-field extract, one arithmetic shift (the
+// negation mask), one shift of the stream and two multiply-adds for the two addresses, instead of four 64-bit shifts, five bit
+// operations, two multiplications and a 64-bit address addition.
+#ifndef FQ_NIBBLE_LADDER
+#define FQ_NIBBLE_LADDER 1
+#endif
+// SIGNED_OUT: hand the ladder's point back on signed limbs (bound 1 each) -- for store_r1_signed, which folds the bias into the canonical
+// reduction of the final store
+template <typename L, typename EF, bool SIGNED_OUT = false> FQ_DEV R1 ladder_endo_nibbles(const EndoNibbles& e, const u32* base, u32 lane_off, const EF& ef) {   // curve4q.py:436-442
+    static_assert(EF::ON, "the fused kernels' ladder: E, F in the lane's LDS rows");
+    Proj<1, 1, 1> q4 = start_table<L>(base + (size_t)(lane_off + (e.top & 7) * (u32)L::ENTRY), 0u);     // s[64] = 1: the entry itself
+    q4.Z = ef.get(e.top & 7, 0);
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+    u32 w[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) w[t] = e.w[t];
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        u32 cur = w[7];
+#pragma unroll
+        for (int t = 7; t > 0; t--) w[t] = w[t - 1];
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            const u32 digit = (cur >> 28) & 7;                                    // top nibble, bits 0..2
+            const u32 neg = (u32)((int32_t)cur >> 31);                            // its bit 3, spread: ~0 when the step subtracts
+            cur <<= 4;
+            EntryRegs t = load_entry<L>(base + (size_t)(lane_off + digit * (u32)L::ENTRY), neg, digit, ef);
+            Fe2<1> T;
+            dblt_asm(Q.X, Q.Y, Q.Z, T);
+            add_asm(Q, T, t, neg);
+        }
+    }
+    if constexpr (SIGNED_OUT) return Q;
+    else return ladder_result<3>(Q);
+}
+// canonical words of a point the asm bodies left on SIGNED limbs (every limb of every coordinate within bound 1): bias, then fe_canon's
+// own carry -- what ladder_result<3> + store_r1 compute, with one carry chain per field element less
+template <int B> FQ_DEV void store_fe2_signed(u64* w, const Fe2<B>& a) {
+    fe_canon(fe_unsign_wide(a.re), w[0], w[1]); fe_canon(fe_unsign_wide(a.im), w[2], w[3]);
+}
+FQ_DEV void store_r1_signed(u64* w, const R1& q) {
+    store_fe2_signed(w, q.X); store_fe2_signed(w + 4, q.Y); store_fe2_signed(w + 8, q.Z); store_fe2_signed(w + 12, q.Ta); store_fe2_signed(w + 16, q.Tb);
+}
 template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, bool TOUCH = false, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
     Proj<1, 1, 1> q4 = start_table<L>(tbl + (code & 7) * stride, (code >> 3) - 1u);
@@ -634,7 +679,11 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
         R1 Q;
         constexpr bool CT_ASM = CT && FQ_LADDER_ASM && ((SRC == LDS && FQ_CT_LDS_ASM) || (SRC == FUSED && FQ_CT_FUSED_ASM));
         constexpr int CH = (((SRC == FUSED || (SRC == LDS && FQ_LDS_ASM) || (SRC == PREBUILT && FQ_PREBUILT_ASM && !DH)) && !CT && FQ_LADDER_ASM) || CT_ASM) ? 3 : LADDER_CH;
-        if (ALGO == ENDO) {
+        if constexpr (ALGO == ENDO && SRC == FUSED && !CT && CH == 3 && FQ_NIBBLE_LADDER) {
+            u64 v[4];
+            decompose(m, v);
+            Q = ladder_endo_nibbles<L, EF, !DH>(recode_nibbles(v), a.scratch, lane_slot * (u32)L::SLOT, ef);      // MUL_*: signed limbs, see the store
+        } else if (ALGO == ENDO) {
             u64 v[4];
             decompose(m, v);
             const EndoDigits e = recode(v);
@@ -688,7 +737,8 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
             }
         } else if (live) {
             u64 o[20];
-            store_r1(o, Q);
+            if constexpr (ALGO == ENDO && SRC == FUSED && !CT && CH == 3 && FQ_NIBBLE_LADDER) store_r1_signed(o, Q);
+            else store_r1(o, Q);
             const bool xyz = SRC == FUSED && (a.io & LADDER_IO_XYZ_OUT);
             uint4* dst = reinterpret_cast<uint4*>(a.out + (xyz ? 12 : 20) * (size_t)id);
 #pragma unroll
@@ -858,14 +908,16 @@ __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, con
             }
             u64 v[4];
             decompose(m, v);
-            const EndoDigits e = recode(v);
             if constexpr (CT) {
+                const EndoDigits e = recode(v);
                 ScanSplit<LdsEF> regs;
                 regs.ef = ef;
                 regs.template load<NDSlots>(slot);
                 Q = ladder_endo_scan<CH>(e, regs);
+            } else if constexpr (CH == 3 && FQ_NIBBLE_LADDER) {          // the headline kernel's ladder (nibble stream, 32-bit entry offsets)
+                Q = ladder_endo_nibbles<NDSlots, LdsEF>(recode_nibbles(v), a.scratch, (blockIdx.x * BLOCK + threadIdx.x) * (u32)NDSlots::SLOT, ef);
             } else {
-                Q = ladder_endo<CH, true, NDSlots, LdsEF>(e, (const u32*)slot, NDSlots::ENTRY, ef);
+                Q = ladder_endo<CH, true, NDSlots, LdsEF>(recode(v), (const u32*)slot, NDSlots::ENTRY, ef);
             }
         } else {
             u64 v[4];

@@ -84,6 +84,41 @@ FQ_DEV EndoDigits recode(const u64 vin[4]) {                             // curv
     r.top = (u32)(v1 + 2 * v2 + 4 * v3);
     return r;
 }
+// The same digits as ONE stream of nibbles for the fused kernels' ladder (round 6: 19 -> 8 glue instructions per ladder step).  Step i
+// (0..63) is nibble i % 8 of word i / 8: bits 0..2 the digit, bit 3 SET when the step SUBTRACTS (sign bit 0, the negation of `sign`
+// above -- so that an arithmetic shift of the nibble's top bit is the negation mask the addition body takes).  The ladder walks the
+// steps from 63 down: it takes the top nibble of word 7 and shifts left.  Built in the same pass as the planes were: no 64-bit
+// variable shifts (`b << i` three times per round above), one 32-bit shift-and-or.
+struct EndoNibbles {
+    u32 w[8];
+    u32 top;
+};
+FQ_DEV EndoNibbles recode_nibbles(const u64 vin[4]) {                     // curve4q.py:358-380
+    EndoNibbles r;
+    u64 s = vin[0] >> 1;                        // bit(v1, i+1), consumed from the bottom
+    u64 v1 = vin[1], v2 = vin[2], v3 = vin[3];
+#pragma unroll
+    for (int t = 0; t < 8; t++) r.w[t] = 0;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        u32 w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 nb1 = ~(u32)s & 1;        // c = (b1 | bj) ^ b1 = ~b1 & bj
+            s >>= 1;
+            const u32 b1 = (u32)v1 & 1, b2 = (u32)v2 & 1, b3 = (u32)v3 & 1;
+            v1 = (v1 >> 1) + (nb1 & b1);
+            v2 = (v2 >> 1) + (nb1 & b2);
+            v3 = (v3 >> 1) + (nb1 & b3);
+            w = (w >> 4) | ((b1 | (b2 << 1) | (b3 << 2) | (nb1 << 3)) << 28);
+        }
+#pragma unroll
+        for (int t = 0; t < 7; t++) r.w[t] = r.w[t + 1];      // word k ends up in w[k] after the eighth push
+        r.w[7] = w;
+    }
+    r.top = (u32)(v1 + 2 * v2 + 4 * v3);
+    return r;
+}
 FQ_DEV u32 endo_digit(const EndoDigits& e, int i) {   // i in 0..63 (wave-uniform)
     return (u32)((e.d[0] >> i) & 1) | ((u32)((e.d[1] >> i) & 1) << 1) | ((u32)((e.d[2] >> i) & 1) << 2);
 }
