@@ -361,8 +361,13 @@ struct LimbSlots {
 // lanes of an XCD keep 5.2 MB of entries against its 4 MiB of L2 (round 3's 96-byte entries, each coordinate padded to 48 bytes for its
 // own aligned loads: 6.3 MB, six loads per gather).  An entry is loaded and stored WHOLE (load_nd / store_nd below); there is no
 // per-coordinate access to this layout.  PARK_P / PARK_Q exist for the builders that park in the slot (none does with this layout).
+// FQ_ND_PACKED=1 (experiment, profiles/r06_gather_experiments.txt): the same slots with N and D as four 128-bit canonical words -- 64 bytes
+// per entry instead of 80, a fifth less gather traffic, for four packs per stored entry and four unpacks per ladder step.
+#ifndef FQ_ND_PACKED
+#define FQ_ND_PACKED 0
+#endif
 struct NDSlots {
-    static constexpr int COORD = 10, ENTRY = 20, PARK_P = 0, PARK_Q = 0, SLOT = 8 * 20;
+    static constexpr int COORD = FQ_ND_PACKED ? 8 : 10, ENTRY = FQ_ND_PACKED ? 16 : 20, PARK_P = 0, PARK_Q = 0, SLOT = 8 * ENTRY;
 };
 // tight limbs (after fe_carry) -> one 128-bit word: fold bits >= 127 (2^127 == 1), ripple once, concatenate
 FQ_DEV uint4 fe_pack128(const Fe<1>& a) {
@@ -404,7 +409,11 @@ template <typename L, typename P> FQ_DEV void store_r2(P* dst, const R2& t) {
 
 // N and D of one entry, whatever the layout: coordinate by coordinate where the layout has coordinates, five 16-byte words for NDSlots
 template <typename L, typename P> FQ_DEV void load_nd(const P* entry, Fe2<1>& N, Fe2<1>& D) {
-    if constexpr (std::is_same<L, NDSlots>::value) {
+    if constexpr (std::is_same<L, NDSlots>::value && FQ_ND_PACKED) {
+        const uint4* q = reinterpret_cast<const uint4*>(entry);
+        const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+        N.re = fe_unpack128(a); N.im = fe_unpack128(b); D.re = fe_unpack128(c); D.im = fe_unpack128(d);
+    } else if constexpr (std::is_same<L, NDSlots>::value) {
         const uint4* q = reinterpret_cast<const uint4*>(entry);
         const uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
         N.re.l[0] = a.x; N.re.l[1] = a.y; N.re.l[2] = a.z; N.re.l[3] = a.w; N.re.l[4] = b.x;
@@ -416,7 +425,10 @@ template <typename L, typename P> FQ_DEV void load_nd(const P* entry, Fe2<1>& N,
     }
 }
 template <typename L, typename P> FQ_DEV void store_nd(P* entry, const Fe2<1>& N, const Fe2<1>& D) {
-    if constexpr (std::is_same<L, NDSlots>::value) {
+    if constexpr (std::is_same<L, NDSlots>::value && FQ_ND_PACKED) {
+        uint4* q = reinterpret_cast<uint4*>(entry);
+        q[0] = fe_pack128(N.re); q[1] = fe_pack128(N.im); q[2] = fe_pack128(D.re); q[3] = fe_pack128(D.im);
+    } else if constexpr (std::is_same<L, NDSlots>::value) {
         uint4* q = reinterpret_cast<uint4*>(entry);
         q[0] = make_uint4(N.re.l[0], N.re.l[1], N.re.l[2], N.re.l[3]);
         q[1] = make_uint4(N.re.l[4], N.im.l[0], N.im.l[1], N.im.l[2]);
