@@ -95,7 +95,8 @@ for wdir in sorted(glob.glob(os.path.join(src, "cfg*"))):
         json.dump(out, fh, indent=1)
     per_workload[w] = step_traffic
     valu_per_workload[w] = step_valu
-    build_ids[w] = ((bench.get("config") or {}).get("library") or {}).get("build_id")
+    cfg = bench.get("config") or {}
+    build_ids[w] = cfg.get("build_id") or (cfg.get("library") or {}).get("build_id")          # the compact line (round 6) / the full record
     print("%s: bench %.4f ms/step, rocprof sum %.4f ms/step, traffic %.1f MB/step (algorithmic %.1f MB)" % (
         w, out["bench_ms_per_step"], out["rocprof_ms_per_step"], step_traffic / 1e6, out["algorithmic_bytes_per_step"] / 1e6))
     for k, r in sorted(kernels.items(), key=lambda kv: -kv[1]["share_of_gpu_time_pct"]):
