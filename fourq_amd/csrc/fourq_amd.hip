@@ -509,6 +509,7 @@ struct fourq_ctx {
     char* pipe_dev = nullptr;      size_t pipe_dev_bytes = 0;
     char* pipe_pin = nullptr;      size_t pipe_pin_bytes = 0;
     u64* diag_stamps = nullptr;    // fourq_diag_clock: 2 x 16 stamps, allocated at its first call
+    hipEvent_t diag_mark = nullptr; // fourq_diag_clock: the end of the stream's backlog at the time of the call
     u64* diag_bracket = nullptr;   // fourq_diag_clock_begin / _stop: 2 x DIAG_STAMP_BLOCKS x {CU key, memtime, memrealtime}
     bool diag_open = false;        // the first stamp launch of a bracket has been enqueued
     bool diag_stopped = false;     // ... and the second
@@ -1332,6 +1333,7 @@ FQ_API int fourq_ctx_destroy(fourq_ctx* c) {
     if (c->zero_copy) (void)hipHostFree(c->zero_copy);
     if (c->diag_stamps) (void)hipFree(c->diag_stamps);
     if (c->diag_bracket) (void)hipFree(c->diag_bracket);
+    if (c->diag_mark) (void)hipEventDestroy(c->diag_mark);
     if (c->shadow_read) (void)hipEventDestroy(c->shadow_read);
     for (hipEvent_t e : c->ticks) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->probe_ticks) if (e) (void)hipEventDestroy(e);
@@ -1931,12 +1933,20 @@ FQ_API int fourq_diag_clock(fourq_ctx* c, uint32_t window_us, double* mhz_median
     if (!c || !mhz_median || window_us == 0 || window_us > 1000000) return FOURQ_ERR_INVALID;
     CtxGuard g(c);
     if (int rc = diag_alloc(c)) return rc;
+    // the end of the stream's backlog as it stands now: still pending when the window has closed = the window lay inside the load
+    if (!c->diag_mark) HIP_TRY(c, hipEventCreateWithFlags(&c->diag_mark, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->diag_mark, c->stream));
     hipLaunchKernelGGL(clock_probe_kernel, dim3(DIAG_BLOCKS), dim3(64), 0, c->copy_out, c->diag_stamps, (u64)window_us * 100u);
     HIP_TRY(c, hipGetLastError());
     int rc = diag_reduce(c, mhz_median, mhz_min, mhz_max, nullptr);
-    // Was the context's stream still busy when the window closed?  If the probe shared a hardware queue with the kernels it waited
-    // behind them and timed an idle chip: the caller must be able to tell.
-    if (under_load) *under_load = hipStreamQuery(c->stream) == hipErrorNotReady ? 1 : 0;
+    // Was the context's stream still busy when the window closed?  If the backlog was shorter than the window -- or the probe shared a hardware
+    // queue with the kernels and waited behind them -- it timed an idle chip: the caller must be able to tell.  (An event, not
+    // hipStreamQuery: that one still answered hipErrorNotReady 19 ms after a 1 ms backlog had drained.)
+    if (under_load) {
+        const hipError_t q = hipEventQuery(c->diag_mark);
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(c, q, "hipEventQuery(diag_mark)");
+        *under_load = q == hipErrorNotReady ? 1 : 0;
+    }
     return rc;
 }
 // The bracket form: begin and stop each enqueue one launch of clock_stamp_kernel on the context's stream -- before and behind the work the

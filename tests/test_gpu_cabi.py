@@ -129,33 +129,30 @@ def test_clock_probe_reads_a_plausible_shader_clock_idle_and_under_load():
 
 
 @pytest.mark.gpu
-def test_clock_probe_says_so_when_it_queued_behind_the_load():
-    """with ONE hardware queue (GPU_MAX_HW_QUEUES=1: a C host that did not raise it, or a process with many streams) the probe's
-    stream shares the kernels' queue and runs only after the backlog has drained -- it then times an idle chip.  fourq_diag_clock reports
-    under_load = 0 in that case and bench.py would discard the reading (clock.valid); with the package's default of 8 queues the same
-    sequence reports 1 (test_clock_probe_reads_a_plausible_shader_clock_idle_and_under_load)."""
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np, torch\n"
-        "sys.path.insert(0, %r)\n"
-        "from bench import seeded_scalars\n"
-        "from fourq_amd import Engine, codec, constants\n"
-        "g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))\n"
-        "dev = torch.device('cuda', 0)\n"
-        "with Engine(0) as e:\n"
-        "    n = e.lanes\n"
-        "    te = e.table_endo(g1)\n"
-        "    s = torch.from_numpy(seeded_scalars(1, n).view(np.int64)).to(dev)\n"
-        "    p = torch.from_numpy(e.mul_endo_fixed(seeded_scalars(2, n), te).view(np.int64)).to(dev)\n"
-        "    out = torch.empty((n, 20), dtype=torch.int64, device=dev)\n"
-        "    for _ in range(200):\n"
-        "        e.mul_endo_dev(s, p, out, n)\n"
-        "    c = e.diag_clock(20000)\n"
-        "    e.sync()\n"
-        "    print('under_load', int(c['under_load']), int(c['mhz']))\n" % ROOT)
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
-    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert proc.returncode == 0, proc.stderr[-2000:]
-    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("under_load")][-1].split()
-    assert line[1] == "0", proc.stdout                      # the probe ran behind the 200 launches: it must not pass for a reading under load
+def test_clock_probe_says_so_when_the_load_did_not_outlast_its_window():
+    """a reading of fourq_diag_clock is the clock UNDER LOAD only if the context's stream was still busy when the window closed.
+    With a backlog shorter than the window (three launches, about a millisecond, against 20 ms) -- or a probe that queued behind the
+    backlog on a shared hardware queue, which looks the same from here -- it reports under_load = 0 and bench.py's `after` mode marks
+    the reading invalid.  (GPU_MAX_HW_QUEUES=1 does not reproduce the shared-queue case on this runtime: the probe's non-blocking stream
+    still ran beside 200 queued launches and read 2 427 MHz; and hipStreamQuery is not the test -- it said "not ready" long after the stream had drained: an event recorded behind the backlog is.)"""
+    import torch
+    from bench import seeded_scalars
+    from fourq_amd import Engine, codec, constants
+    dev = torch.device("cuda", 0)
+    g1 = codec.pack_point((constants.Gx, constants.Gy, (1, 0), constants.Gx, constants.Gy))
+    with Engine(0) as e:
+        n = e.lanes
+        te = e.table_endo(g1)
+        s = torch.from_numpy(seeded_scalars(8201, n).view(np.int64)).to(dev)
+        p = torch.from_numpy(e.mul_endo_fixed(seeded_scalars(8202, n), te).view(np.int64)).to(dev)
+        out = torch.empty((n, 20), dtype=torch.int64, device=dev)
+        for _ in range(3):
+            e.mul_endo_dev(s, p, out, n)
+        short = e.diag_clock(20000)
+        e.sync()
+        assert short["under_load"] is False, short
+        for _ in range(400):                                    # ~120 ms queued: the window lies inside it
+            e.mul_endo_dev(s, p, out, n)
+        long = e.diag_clock(20000)
+        e.sync()
+        assert long["under_load"] is True, long
