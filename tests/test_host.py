@@ -271,8 +271,10 @@ def test_null_arguments_are_rejected_without_a_device():
 
 
 def test_documents_quote_the_committed_bench_line():
-    """DESIGN.md section 6 and README.md carry numbers generated from profiles/r05_bench_driver_args.json (the driver's protocol); the
-    generator's --check mode must find nothing to change, and neither document has a line a reviewer has to scroll sideways for."""
+    """DESIGN.md section 6 and README.md carry numbers generated from the driver's own record (BENCH_rNN.json.parsed, newest parsed one, stated
+    first) and from profiles/r06_bench_driver_args_run*.full.json (the builder's runs of the driver's protocol); the generator's --check mode must
+    find nothing to change, and neither document has a line a reviewer has to scroll sideways for.  The committed compact lines are what the
+    driver reads: at most 6 144 bytes each, and bench.compact_line reproduces them from the committed full records."""
     tool = os.path.join(ROOT, "tools", "sync_design_numbers.py")
     proc = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True)
     assert proc.returncode == 0, proc.stderr
@@ -280,3 +282,14 @@ def test_documents_quote_the_committed_bench_line():
         long = [i + 1 for i, ln in enumerate(open(os.path.join(ROOT, doc), encoding="utf-8").read().split("\n")) if len(ln) > 200]
         assert not long, "%s: lines %s are longer than 200 characters" % (doc, long[:5])
     assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) < 48 * 1024       # the current design only; the rest is HISTORY.md
+    import json
+    import bench
+    for k in (1, 2, 3):
+        line = open(os.path.join(ROOT, "profiles", "r06_bench_driver_args_run%d.json" % k)).read().strip()
+        with open(os.path.join(ROOT, "profiles", "r06_bench_driver_args_run%d.full.json" % k)) as fh:
+            full = json.load(fh)
+        assert len(line) <= bench.LINE_MAX_BYTES and "\n" not in line
+        assert json.loads(bench.compact_line(full)) == json.loads(line)
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "roofline", "cpu_baseline"):
+            assert key in json.loads(line), key

@@ -5,15 +5,21 @@ and the profile they cite cannot drift apart (and quote the DRIVER'S protocol, n
     python tools/sync_design_numbers.py            # rewrite the blocks between the BEGIN / END markers
     python tools/sync_design_numbers.py --check    # exit 1 if a block differs from what the profile says; writes nothing
 
-Source: profiles/r05_bench_driver_args.json = the JSON line of `python bench.py --steps 20 --warmup 5` on one MI355X.
+Sources, in this order:
+  1. the DRIVER'S own record of the newest round, BENCH_rNN.json at the repo root, when its `parsed` line exists -- stated first, with the
+     build id it was taken on (it is the previous round's build until the driver has run this one);
+  2. profiles/r06_bench_driver_args_run{1,2,3}.full.json = the full records (bench_full.json) of three runs of
+     `python bench.py --steps 20 --warmup 5` on one MI355X by the builder; the tables are run 1's.
 """
+import glob
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCE = os.path.join("profiles", "r05_bench_driver_args.json")
+SOURCE = os.path.join("profiles", "r06_bench_driver_args_run1.full.json")
+RUNS = [os.path.join("profiles", "r06_bench_driver_args_run%d.full.json" % k) for k in (2, 3)]
 BEGIN = "<!-- BEGIN numbers (tools/sync_design_numbers.py) -->"
 END = "<!-- END numbers -->"
 
@@ -34,7 +40,8 @@ def design_block(d):
     for k in ("cfg3", "cfg4", "cfg5"):
         r = d["configs"][k]
         rows.append((names[k], r, r["roofline"], r["valu_roofline"], d.get("ct_select", {}).get(k)))
-    out = ["Build `%s`, `%s`. The headline on this round's boxes, same protocol:" % (lib["build_id"], SOURCE), runs_sentence(d) + ".", "",
+    out = [driver_sentence(lib["build_id"]), "",
+           "Build `%s`, `%s` (+ runs 2, 3). The headline of the builder's three runs of the same protocol:" % (lib["build_id"], SOURCE), runs_sentence(d) + ".", "",
            "| configuration (per GPU) | units/s | ms / step | in-kernel clock | cycles / unit | `issue` | algorithmic / executed frac | traffic vs algorithmic | constant-time |",
            "|---|---|---|---|---|---|---|---|---|"]
     for name, r, roof, valu, ct in rows:
@@ -55,6 +62,11 @@ def design_block(d):
             "| affine in / out, 160 B | %s ms = %s/s | %s ms = **%s/s** (%d chunks) |" % (ms(p["affine"]["ms_per_step"]), e8(p["affine"]["value"]), ms(big["affine"]["ms_per_step"]), e8(big["affine"]["value"]), big["affine"]["chunks"]),
             "| 32-byte points in / out, 97 B | %s ms = %s/s | %s ms = **%s/s** (%d chunks) |" % (ms(p["bytes"]["ms_per_step"]), e8(p["bytes"]["value"]), ms(big["bytes"]["ms_per_step"]), e8(big["bytes"]["value"]), big["bytes"]["chunks"]),
             ""]
+    if "ct_r1" in big:
+        c = big["ct_r1"]
+        out += ["The 2²⁰ raw-R1 call on the constant-time context: %s ms = %s/s in %d chunks planned with its own measured %.2f ns per element — %.3f of its floor (constant-time kernels"
+                % (ms(c["ms_per_step"]), e8(c["value"]), c["chunks"], c["planned_kernel_ns_per_elem"], c["over_floor"]),
+                "device-resident for 2²⁰ + one generation's copy in and out = %s ms)." % ms(c["floor_ms"]), ""]
     hosts = []
     for k, what in (("cfg3", "cfg3's call (scalars in, R1 out)"), ("cfg4", "cfg4's exchange call"), ("cfg5", "cfg5's mixed call")):
         q = d["configs"][k]["pcie_inclusive"]
@@ -73,16 +85,18 @@ def design_block(d):
         out.append("%s; t(65 792) / t(65 536) = %.2f." % (" / ".join("%.3f" % sw[s] for s in sizes), sw["t(65792)/t(65536)"]))
     c = d.get("cpu_baseline")
     if c:
-        out.append("CPU baseline: pure-Python oracle %.2g mults/s on %d cores; C restatement %.2g/s on %d threads." % (
-            c["value"], c["cores"], c["c_restatement"]["value"], c["c_restatement"]["threads"]))
+        out.append("CPU baseline (`kind: port`): pure-Python oracle %.3g mults/s on %d of the box's %d cores (%d granted, cap %d) = %.0f per core — the reference's own code does"
+                   % (c["value"], c["cores"], c["host_cores_total"], c["host_cores_granted"], c["cores_cap"], c["per_core"]))
+        out.append("%.0f per core (SURVEY §6): the port is faster than what it restates; C restatement %.3g/s on %d threads." % (
+            c["per_core_reference_survey"], c["c_restatement"]["value"], c["c_restatement"]["threads"]))
     return "\n".join(out)
 
 
 def earlier_runs():
-    """The same protocol on other boxes of the pool this round (builds that differ only in host code: the kernels are round 4's)."""
+    """The other runs of the protocol on this round's build (RUNS)."""
     runs = []
-    for k in (1, 2, 3, 4):
-        path = os.path.join(ROOT, "profiles", "r05_bench_driver_args_run%d.json" % k)
+    for rel in RUNS:
+        path = os.path.join(ROOT, rel)
         if os.path.exists(path):
             with open(path) as fh:
                 runs.append(json.load(fh))
@@ -90,23 +104,54 @@ def earlier_runs():
 
 
 def runs_sentence(d):
-    runs = earlier_runs() + [d]
+    runs = [d] + earlier_runs()
     return "; ".join("%s at %.0f MHz = %.2f cycles per element" % (e8(r["value"]), r["clock"]["in_kernel_mhz"], r["cycles_per_unit"]) for r in runs)
+
+
+def driver_record():
+    """(round number, parsed line) of the newest BENCH_rNN.json at the repo root that the driver could parse, or None."""
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "BENCH_r*.json")):
+        m = re.search(r"BENCH_r(\d+)\.json$", path)
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if m and isinstance(rec.get("parsed"), dict) and "value" in rec["parsed"] and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), rec["parsed"])
+    return best
+
+
+def driver_sentence(build_id):
+    rec = driver_record()
+    if rec is None:
+        return "**Driver's record:** none parsed yet."
+    rnd, line = rec
+    cfg = line.get("config") or {}
+    theirs = cfg.get("build_id") or (cfg.get("library") or {}).get("build_id")
+    roof = line.get("roofline") or {}
+    same = theirs == build_id
+    return ("**Driver's record (`BENCH_r%02d.json.parsed`, %s):**\n%s %s at %s ms per step, `roofline.frac` %s.%s" % (
+        rnd, "this build" if same else "round %d's build, the newest record the driver could parse — round 5's 22 KB line was not" % rnd,
+        e8(line["value"]), line.get("unit", ""), ms(line["ms_per_step"]), roof.get("frac"),
+        "" if same else "\nThe driver has not run this round's build yet; what it will read is the compact line the figures below come from."))
 
 
 def readme_block(d):
     c = d["configs"]
     big = d["pcie_inclusive"]["at_2^20"]
-    vals = [r["value"] for r in earlier_runs() + [d]]
-    head = e8(d["value"]) if len(vals) == 1 else "%.2f–%s" % (min(vals) / 1e8, e8(max(vals)))
-    return ("Numbers of `python bench.py --steps 20 --warmup 5` — the driver's protocol — on one MI355X (`%s`). Boxes of the pool hold clocks\n"
-            "several percent apart under the same kernel, so the line carries the in-kernel clock and cycles per unit; this round's runs of the protocol:\n"
+    vals = [r["value"] for r in [d] + earlier_runs()]
+    head = e8(d["value"]) if e8(min(vals)) == e8(max(vals)) else "%.2f–%s" % (min(vals) / 1e8, e8(max(vals)))
+    return ("%s\n\n"
+            "Numbers of `python bench.py --steps 20 --warmup 5` — the driver's protocol — on one MI355X (`%s`). Boxes of the pool hold clocks\n"
+            "several percent apart under the same kernel, so the line carries the clock of the timed steps and cycles per unit; the builder's three runs:\n"
             "%s.\n"
             "**%s** variable-base scalar multiplications per second at a batch of 2¹⁶ (device-resident;\n"
             "%s/s from pinned host arrays at 2²⁰, PCIe included), %s fixed-base `MUL_windowed`/s, %s Diffie-Hellman exchanges/s,\n"
             "%s/s on the 50/50 fixed / variable mix (one persistent kernel pulling work items off a device-side queue), every output checked\n"
-            "bit-exact against the C restatement of the reference in the same run; the pure-Python path does %.1g/s on the same box's %d cores." % (
-                SOURCE, runs_sentence(d), head, e8(big["r1"]["value"]), e8(c["cfg3"]["value"]), e8(c["cfg4"]["value"]),
+            "bit-exact against the C restatement of the reference in the same run; the pure-Python path does %.3g/s on %d cores of the same box." % (
+                driver_sentence(d["config"]["library"]["build_id"]), SOURCE, runs_sentence(d), head, e8(big["r1"]["value"]), e8(c["cfg3"]["value"]), e8(c["cfg4"]["value"]),
                 e8(c["cfg5"]["value"]), d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"]))
 
 
