@@ -96,6 +96,38 @@ def test_full_batch_cfg2_vs_c_oracle(eng):
     assert np.array_equal(gotw, oc.mul(oc.WINDOWED, s[:8192], pts[:8192]))
 
 
+def test_edge_scalars_through_the_one_lane_kernels(eng):
+    """The reference's edge scalars reach the GPU suite on SMALL batches, i.e. on the two- and four-lane kernels.  The fused one-lane
+    kernels -- round 6: digits as a nibble stream (recode_nibbles), 32-bit entry offsets, the signed store -- run from more than half a
+    generation on: a whole generation whose head holds every edge pattern of the recoding (0, 1, 2, N-1, N, N+1, 2N, 2^255, 2^256-1,
+    single words of ones, alternating bits, lone top and bottom bits of every 64-bit word), rest random; every output against the C
+    oracle: MUL_endo, DH_endo (the same fused ladder, DH flavour), the mixed batch (mixed_queue_kernel's variable-base items) and the
+    affine flavour (fused I/O flags)."""
+    n = eng.lanes
+    N = o.N
+    edge = [0, 1, 2, N - 1, N, N + 1, 2 * N, 1 << 255, (1 << 256) - 1, (1 << 64) - 1, ((1 << 64) - 1) << 64, ((1 << 64) - 1) << 128, ((1 << 64) - 1) << 192,
+            int("55" * 32, 16), int("aa" * 32, 16), (1 << 256) - 2, (1 << 255) - 1]
+    edge += [1 << (64 * w) for w in range(4)] + [1 << (64 * w + 63) for w in range(4)] + [(1 << 256) - 1 - (1 << (64 * w)) for w in range(4)]
+    s = seeded_scalars(4501, n)
+    s[:len(edge)] = codec.pack_scalars(edge)
+    pts = torsion_points(eng, 4502, n)
+    want = oc.mul(oc.ENDO, s, pts)
+    assert np.array_equal(eng.mul_endo(s, pts), want)
+    aff = oc.r1_to_affine(pts)
+    out, st = eng.dh_endo(s, aff)
+    want_dh, want_st = oc.dh(oc.ENDO, s, aff)
+    assert np.array_equal(st, want_st) and np.array_equal(out, want_dh)
+    lifted = np.zeros((n, 20), dtype=np.uint64)
+    lifted[:, 0:8] = aff; lifted[:, 8] = 1; lifted[:, 12:20] = aff
+    assert np.array_equal(eng.mul_affine(s, aff), oc.r1_to_affine(oc.mul(oc.ENDO, s, lifted)))
+    n2 = 2 * n                                                  # mixed: variable-base items at the head (flags 1), fixed-base behind
+    s2 = np.concatenate([s, s]); p2 = np.concatenate([pts, pts])
+    flags = np.concatenate([np.ones(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)])
+    te = oc.table(oc.ENDO, codec.pack_point(G1))
+    got = eng.mul_endo_mixed(s2, p2, flags, te)
+    assert np.array_equal(got[:n], want) and np.array_equal(got[n:], oc.mul(oc.ENDO, s, None, te))
+
+
 def test_full_batch_cfg3_fixed_base(eng):
     """BASELINE.json config 3: 2^20 fixed-base MUL_windowed(m, G, table): a 2^15 slice against the C oracle,
     and on the whole batch the size-independent property MUL_windowed == MUL_endo as affine points

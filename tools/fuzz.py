@@ -64,7 +64,11 @@ while time.time() < t_end:
         knobs["FOURQ_PIPE_GENS"] = rng.choice(["0", "1", "2", "3"])
         if rng.random() < 0.3:
             knobs["FOURQ_PIPE_HOST_WAIT"] = "1"
-    for k in ("FOURQ_PIPE_SLOTS", "FOURQ_PIPE_GENS", "FOURQ_PIPE_HOST_WAIT", "FOURQ_PAIR_MAX", "FOURQ_QUAD_MAX", "FOURQ_HOST_ZERO_COPY", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
+    if rng.random() < 0.25:                                            # round 6: the affine / encoded flavours through lift + R1 rows instead of the fused I/O flags
+        knobs["FOURQ_FUSED_IO"] = "0"
+    if rng.random() < 0.25:                                            # ... and chunk plans from the compiled-in guesses instead of the context's measurements
+        knobs["FOURQ_PIPE_MEASURE"] = "0"
+    for k in ("FOURQ_FUSED_IO", "FOURQ_PIPE_MEASURE", "FOURQ_PIPE_SLOTS", "FOURQ_PIPE_GENS", "FOURQ_PIPE_HOST_WAIT", "FOURQ_PAIR_MAX", "FOURQ_QUAD_MAX", "FOURQ_HOST_ZERO_COPY", "FOURQ_SPLIT_MIN", "FOURQ_SPLIT_CHUNK", "FOURQ_NORM_K", "FOURQ_SPLIT_ALL", "FOURQ_SPLIT_ENDO_MIN", "FOURQ_CT_SELECT", "FOURQ_HOST_BOUNCE", "FOURQ_MIXED_QUEUE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     with Engine(0) as eng:
