@@ -293,3 +293,20 @@ def test_documents_quote_the_committed_bench_line():
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                     "config", "roofline", "cpu_baseline"):
             assert key in json.loads(line), key
+
+
+def test_compact_line_refuses_to_outgrow_the_driver():
+    """the line grew round by round until the driver could not read it.  bench.compact_line takes numbers and short labels from
+    the full record and REFUSES (SystemExit, no line at all) to print more than LINE_MAX_BYTES; strings are cut to their label length."""
+    import json
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r06_bench_driver_args_run1.full.json")) as fh:
+        full = json.load(fh)
+    line = bench.compact_line(full)
+    assert len(line) < 3000 and json.loads(line)["roofline"]["frac"] == full["roofline"]["frac"]
+    bloated = json.loads(json.dumps(full))
+    bloated["cpu_baseline"]["sample"] = "x" * 5000                       # prose creeping back in: cut to 160 characters
+    assert len(json.loads(bench.compact_line(bloated))["cpu_baseline"]["sample"]) == 160
+    bloated["configs"] = {"cfg%d" % k: bloated["configs"]["cfg3"] for k in range(3, 60)}      # ... or records: refused
+    with pytest.raises(SystemExit, match="over the"):
+        bench.compact_line(bloated)
