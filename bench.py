@@ -209,8 +209,8 @@ def c_oracle_gate(workload, data, got_words, world=1):
 
 def edge_case_check(eng):
     """SURVEY.md 8d: every run carries an edge-case mini-batch -- scalars {0,1,2,N-1,N,N+1,2N,2^255,2^256-1}
-    on G and -G through MUL_endo, MUL_windowed and DH_endo, bit-exact against the Python oracle (part of the
-    cpu_baseline leg: the oracle is the checker).  Returns the number of cases."""
+    on G and -G through MUL_endo, MUL_windowed and DH_endo, bit-exact against the Python oracle (the oracle is the
+    checker; part of every rank's parity gate).  Returns the number of cases."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import curve4q_oracle as o
     from fourq_amd import codec
@@ -1023,6 +1023,8 @@ def main():
     steps = args.steps or wl["steps"]
     rec, d = b.run(args.workload, n, steps, args.warmup)
     parity, got, want = ({"gate": "skipped (--no-parity)", "ok": None}, None, None) if args.no_parity else b.parity_gate(args.workload, d)
+    if not args.no_parity:                                  # the edge-case mini-batch belongs to EVERY run, on every rank (raises on a difference)
+        parity["edge_cases_checked"] = edge_case_check(b.eng)
     gather = b.gather_ms(d["out"], n) if world > 1 else None
     alongside = None
     if rank == 0 and args.workload in ("cfg2", "cfg3") and not args.no_alongside and not args.no_parity:
@@ -1113,7 +1115,7 @@ def main():
             full["cpu_baseline"]["c_restatement"] = {
                 "value": parity["c_oracle_units_per_s"], "unit": "scalar-mults/s", "threads": parity["c_oracle_threads"], "cores": host_cores(), "kind": "port",
                 "sample": "whole batch (%d units) via oracle/fourq_oracle.c (OpenMP), every output compared bit-exact with the GPU's" % n}
-            full["cpu_baseline"]["edge_cases_checked"] = edge_case_check(b.eng)
+            full["cpu_baseline"]["edge_cases_checked"] = parity.get("edge_cases_checked")
         emit(full, args.full_json)
     if getattr(b, "eng_ct", None) is not None:
         b.eng_ct.close()

@@ -39,6 +39,16 @@ class OracleEngine:
         if os.environ.get("FOURQ_STANDIN_CORRUPT_RANK") == os.environ.get("RANK"):       # tests: this rank's gate must catch it and stop the job
             _np(out)[n // 2, 3] ^= 1
 
+    # the host-array calls of the edge-case mini-batch (bench.edge_case_check: every rank, every run)
+    def mul_endo(self, scalars, points_r1):
+        return oc.mul(oc.ENDO, np.ascontiguousarray(scalars), np.ascontiguousarray(points_r1))
+
+    def mul_windowed(self, scalars, points_r1):
+        return oc.mul(oc.WINDOWED, np.ascontiguousarray(scalars), np.ascontiguousarray(points_r1))
+
+    def dh_endo(self, scalars, points_affine):
+        return oc.dh(oc.ENDO, np.ascontiguousarray(scalars), np.ascontiguousarray(points_affine))
+
     def diag_clock(self, window_us):
         return {"mhz": 1000.0, "mhz_min": 1000.0, "mhz_max": 1000.0, "window_us": window_us}     # no shader clock on a CPU: a placeholder
 

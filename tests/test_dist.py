@@ -189,6 +189,7 @@ def test_bench_rank_body_runs_world_2_over_gloo_without_a_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["scaling"] == "weak"
     assert line["config"]["backend"].startswith("gloo")
     assert line["parity_ok"] is True and full["parity"]["ok"] is True and full["parity"]["all_ranks_ok"] is True and full["parity"]["units"] == 384
+    assert full["parity"]["edge_cases_checked"] == 54                                                           # the edge-case mini-batch ran on the ranks too
     assert line["gather_ms"] > 0 and line["steps"] == 2 and "cpu_baseline" not in line
     lo, hi = line["cycles_per_unit_ranks"]
     assert 0 < lo <= hi

@@ -93,7 +93,7 @@ def test_default_line_has_the_contract_keys(tmp_path):
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "oracle/curve4q_oracle.py" in c["sample"]
     assert c["c_restatement"]["threads"] == c["c_restatement"]["cores"]                              # OpenMP took the thread count
-    assert line["parity"]["ok"] is True and line["parity"]["units"] == 1 << 16
+    assert line["parity"]["ok"] is True and line["parity"]["units"] == 1 << 16 and line["parity"]["edge_cases_checked"] == 54
     assert set(line["configs"]) == {"cfg3", "cfg4", "cfg5"}
     for name, rec in line["configs"].items():
         assert rec["parity"]["ok"] is True and rec["ms_per_step"] > 0 and rec["roofline"]["frac"] > 0, name
