@@ -293,9 +293,12 @@ GPU = _Cuda()
 
 
 class Bench:
-    def __init__(self, rank, local_rank, world, rehearse):
+    def __init__(self, rank, local_rank, world, rehearse, dist_on=None):
         from fourq_amd import codec, constants
         self.rank, self.world, self.rehearse = rank, world, rehearse
+        # the rank body's collectives run whenever a process group exists: N > 1, or FOURQ_BENCH_FORCE_DIST=1 (a group of ONE rank over nccl:
+        # the only way to drive the RCCL branch of this file on a one-GPU box; tests/test_gpu_multi.py)
+        self.dist_on = (world > 1) if dist_on is None else dist_on
         GPU.set_device(local_rank)
         self.local_rank = local_rank
         self.dev = GPU.device(local_rank)
@@ -390,7 +393,7 @@ class Bench:
             step()
         ev0, ev1 = GPU.event(), GPU.event()
         GPU.synchronize()
-        if self.world > 1:
+        if self.dist_on:
             dist.barrier()
         GPU.synchronize()
         # The shader clock OF the timed steps: two launches of a stamp kernel on the launch stream, one before the first
@@ -408,7 +411,7 @@ class Bench:
         if bracket:
             self.eng.diag_clock_stop()               # enqueues; the host does not wait here
         GPU.synchronize()
-        if self.world > 1:
+        if self.dist_on:
             dist.barrier()
         GPU.synchronize()
         elapsed = time.perf_counter() - t0
@@ -422,7 +425,7 @@ class Bench:
             clock = {"in_kernel_mhz": round(c["mhz"], 1), "min_mhz": round(c["mhz_min"], 1), "max_mhz": round(c["mhz_max"], 1),
                      "window_ms": round(c["window_us"] * 1e-3, 3), "mode": "bracket", "window_over_timed_span": round(covered, 4),
                      "valid": bool(abs(c["window_us"] * 1e-3 - span_ms) <= 0.02 * span_ms + 0.2)}
-        if self.world > 1:
+        if self.dist_on:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.rehearse else self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -1010,13 +1013,15 @@ def main():
     if rehearse:
         local_rank = 0
     GPU.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or os.environ.get("FOURQ_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         import datetime
         # a rank that dies (its parity gate raises) must take the job down, not leave the others waiting for ever
         dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=int(os.environ.get("FOURQ_BENCH_PG_TIMEOUT_S", "600"))))
-    b = Bench(rank, local_rank, world, rehearse)
+    b = Bench(rank, local_rank, world, rehearse, dist_on)
 
     wl = WORKLOADS[args.workload]
     n = args.batch or wl["batch"]
@@ -1025,7 +1030,7 @@ def main():
     parity, got, want = ({"gate": "skipped (--no-parity)", "ok": None}, None, None) if args.no_parity else b.parity_gate(args.workload, d)
     if not args.no_parity:                                  # the edge-case mini-batch belongs to EVERY run, on every rank (raises on a difference)
         parity["edge_cases_checked"] = edge_case_check(b.eng)
-    gather = b.gather_ms(d["out"], n) if world > 1 else None
+    gather = b.gather_ms(d["out"], n) if dist_on else None
     alongside = None
     if rank == 0 and args.workload in ("cfg2", "cfg3") and not args.no_alongside and not args.no_parity:
         alongside = b.alongside(args.workload, d, steps=100 if args.workload == "cfg2" else 20)
@@ -1045,7 +1050,7 @@ def main():
             r["parity"], want_w = {"gate": "skipped (--no-parity)", "ok": None}, None
         else:
             r["parity"], _, want_w = b.parity_gate(w, dw)
-        if world > 1 and w == "cfg4":
+        if dist_on and w == "cfg4":
             r["gather_ms"] = b.gather_ms(dw["out"], WORKLOADS[w]["batch"])
         if world == 1 and not args.no_pcie and want_w is not None:
             r["pcie_inclusive"] = b.pcie_inclusive(w, dw, want_w, reps=pcie_reps[w])
@@ -1058,7 +1063,7 @@ def main():
             ct[w] = b.ct_select_record(w, WORKLOADS[w]["batch"], max(5, WORKLOADS[w]["steps"] // 5), 2, want_w, r["ms_per_step"])
 
     ranks_seen, cyc_range = 1, None
-    if world > 1:                                           # every rank passed its own gate, or the job has already died
+    if dist_on:                                             # every rank passed its own gate, or the job has already died
         where = "cpu" if rehearse else b.dev
         ok = torch.tensor([1.0 if parity["ok"] in (True, None) else 0.0], device=where)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -1085,7 +1090,7 @@ def main():
                        "clock_settle_ms": b.settle_ms, "table_selection": "constant-time" if b.eng.ct_select else "indexed",
                        "library": {"version": b.eng.version, "build_id": b.eng.build_id, "built_from_these_sources": _built_from_sources()},
                        "ranks_seen": ranks_seen,
-                       "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if world > 1 else None},
+                       "backend": ("gloo (rehearsal: every rank on GPU 0)" if rehearse else "nccl (RCCL)") if dist_on else None},
             "roofline": rec["roofline"], "valu_roofline": rec["valu_roofline"], "parity": parity,
             "clock": rec["clock"], "cycles_per_unit": rec["cycles_per_unit"], "kernel_cycles_per_step": rec["kernel_cycles_per_step"],
             "fields": "profiles/BENCH_FIELDS.md",
@@ -1120,7 +1125,7 @@ def main():
     if getattr(b, "eng_ct", None) is not None:
         b.eng_ct.close()
     b.eng.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

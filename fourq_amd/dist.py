@@ -39,8 +39,8 @@ def gather_rows(local, n_total, dst=0, group=None):
     shard for the collective and `dst` trims.  Returns the full tensor on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local
+    if not dist.is_initialized():
+        return local                          # (a group of ONE rank still goes through the collective: same code, same result)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if dist.get_backend(group) == "gloo" and local.is_cuda:
         local = local.cpu()                   # rehearsals on one GPU: gloo gathers host tensors only

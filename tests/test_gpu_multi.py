@@ -229,3 +229,64 @@ def test_concurrent_single_calls_are_combined():
     assert stats["mul_endo"]["calls"] - before.get("mul_endo", 0) == T * R and stats["dh_endo"]["calls"] - before.get("dh_endo", 0) == T * R
     assert stats["mul_endo"]["batches"] < stats["mul_endo"]["calls"] and stats["mul_endo"]["largest_batch"] > 1
     assert stats["keygen_comb"]["calls"] - before.get("keygen_comb", 0) == (T - 1) * (R // 5)
+
+
+def test_rccl_loads_and_runs_collectives_on_this_image():
+    """The pool gives this build one GPU, so no multi-rank RCCL job can run here -- but the backend bench.py --gpus N uses ("nccl" IS RCCL
+    on ROCm) can at least be initialised and driven through the calls the rank body makes: barrier, all_reduce(MAX / MIN / SUM) on the
+    tensors bench.py reduces, and the gather of fourq_amd.dist.gather_rows' padded buffers, on a process group of ONE rank in a fresh
+    process (a group of one still loads librccl, creates a communicator on the device and enqueues its kernels on the stream)."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = (
+        "import datetime, torch, torch.distributed as dist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))\n"
+        "dev = torch.device('cuda', 0)\n"
+        "dist.barrier()\n"
+        "t = torch.tensor([1.25], dtype=torch.float64, device=dev)\n"
+        "for op in (dist.ReduceOp.MAX, dist.ReduceOp.MIN, dist.ReduceOp.SUM):\n"
+        "    dist.all_reduce(t, op=op)\n"
+        "assert float(t.item()) == 1.25\n"
+        "pad = torch.arange(8 * 524288, dtype=torch.int64, device=dev).reshape(524288, 8)      # config 4's shard: 2^19 affine rows\n"
+        "bufs = [torch.empty_like(pad)]\n"
+        "dist.gather(pad, bufs, dst=0)\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(bufs[0], pad)\n"
+        "print('backend', dist.get_backend(), 'ok')\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(var, None)
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert "backend nccl ok" in proc.stdout
+
+
+def test_bench_rank_body_over_rccl_with_a_group_of_one():
+    """bench.py's `nccl` branch had never executed.  FOURQ_BENCH_FORCE_DIST=1 makes the UNMODIFIED rank body create its
+    process group and run every collective it runs at N > 1 -- the barriers around the timed steps, the MAX over ranks, the MIN / SUM of
+    the parity verdicts, the per-rank cycles' MIN / MAX, the gather of results (fourq_amd.dist.gather_rows) -- over RCCL, on a group of
+    one rank: all that a one-GPU box can offer, and it is the same code path an 8-GPU job takes."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, FOURQ_BENCH_FORCE_DIST="1", FOURQ_BENCH_SETTLE_MS="10", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FOURQ_BENCH_REHEARSE", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-pcie", "--no-ct",
+                           "--no-alongside", "--full-json", ""], capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 6144
+    line = json.loads(lines[0])
+    assert line["config"]["backend"] == "nccl (RCCL)" and line["config"]["ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert line["parity_ok"] is True and line["gather_ms"] > 0
+    lo, hi = line["cycles_per_unit_ranks"]
+    assert lo == hi == line["cycles_per_unit"]
+    assert line["configs"]["cfg4"]["gather_ms"] > 0 and all(c["parity_ok"] for c in line["configs"].values())
