@@ -1021,6 +1021,17 @@ def main():
         # a rank that dies (its parity gate raises) must take the job down, not leave the others waiting for ever
         dist.init_process_group(backend="gloo" if rehearse else "nccl", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=int(os.environ.get("FOURQ_BENCH_PG_TIMEOUT_S", "600"))))
+        # RCCL builds its communicator at the FIRST collective (hundreds of milliseconds, the GPU idle meanwhile).  Left to the barrier in
+        # front of the timed steps, that wait let the clock governor fall back right before the measurement: 20 timed steps at 1 891 MHz
+        # instead of 2 365 -- 1.67 x 10^8/s instead of 2.2 (profiles/r06_rccl_group_of_one.txt).  So: every collective the rank body uses,
+        # once, here, before anything is timed.
+        where = "cpu" if rehearse else torch.device("cuda", local_rank)
+        dist.barrier()
+        for op in (dist.ReduceOp.MAX, dist.ReduceOp.MIN, dist.ReduceOp.SUM):
+            dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=where), op=op)
+        from fourq_amd.dist import gather_rows
+        gather_rows(torch.zeros((16, 8), dtype=torch.int64, device=where), 16 * world, dst=0)
+        GPU.synchronize()
     b = Bench(rank, local_rank, world, rehearse, dist_on)
 
     wl = WORKLOADS[args.workload]
