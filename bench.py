@@ -381,6 +381,11 @@ class Bench:
         wl = WORKLOADS[workload]
         step, d = self.prepare(workload, n)
         GPU.synchronize()
+        if self.dist_on:
+            # Align the ranks BEFORE the clock is settled: a rank that reaches the contract's barrier (below) milliseconds ahead of the slowest
+            # one idles there while its clock falls back, and the MAX over ranks then times that rank's ramp instead of its kernels.  After
+            # this barrier every rank does the same time-based settle loop and the same W warm-up steps, and they arrive together.
+            dist.barrier()
         # The clock governor needs ~35 ms of load to reach the sustained clock (tools/clock_ramp.py,
         # profiles/clock_ramp_r01.txt: 0.43 ms per launch cold, 0.364 ms from launch 100 on).  Throughput is a
         # sustained-rate metric, so the device is brought to that state before the W warm-up steps; untimed.
