@@ -763,9 +763,9 @@ int dh_dev(fourq_ctx* c, int algo, const uint64_t* scalars, const uint64_t* poin
         return algo == ENDO ? launch_pair<ENDO, true, true>(c, a) : launch_pair<WINDOWED, true, true>(c, a);
     }
     int group = normalize_group(c, n);
-    if (!table) {                                  // fused kernels invert in place; the prep + ladder route always defers
-        const bool split = variable_route(c, algo, true, n, false) == ROUTE_SPLIT;
-        group = split ? (group ? group : 1) : 0;
+    if (!table) {                                  // the prep + ladder route always defers; the fused kernels from two generations on (K = 2, 4, 8), except
+        const Route route = variable_route(c, algo, true, n, false);     // with a two-lane tail, whose kernels invert in place
+        group = route == ROUTE_SPLIT ? (group ? group : 1) : (route == ROUTE_FUSED && FQ_FUSED_DEFER ? group : 0);
     }
     int rc = group ? ensure_proj(c, n) : FOURQ_OK;
     if (rc) return rc;

@@ -360,6 +360,11 @@ template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = L
 #ifndef FQ_NIBBLE_LADDER
 #define FQ_NIBBLE_LADDER 1
 #endif
+// DH batches of at least two generations on the fused kernels leave (X, Y, Z) for normalize_kernel<K> as the other routes do (round 6), instead
+// of inverting per element at one wave per SIMD
+#ifndef FQ_FUSED_DEFER
+#define FQ_FUSED_DEFER 1
+#endif
 // SIGNED_OUT: hand the ladder's point back on signed limbs (bound 1 each) -- for store_r1_signed, which folds the bias into the canonical
 // reduction of the final store
 template <typename L, typename EF, bool SIGNED_OUT = false> FQ_DEV R1 ladder_endo_nibbles(const EndoNibbles& e, const u32* base, u32 lane_off, const EF& ef) {   // curve4q.py:436-442
@@ -396,6 +401,33 @@ template <int B> FQ_DEV void store_fe2_signed(u64* w, const Fe2<B>& a) {
 }
 FQ_DEV void store_r1_signed(u64* w, const R1& q) {
     store_fe2_signed(w, q.X); store_fe2_signed(w + 4, q.Y); store_fe2_signed(w + 8, q.Z); store_fe2_signed(w + 12, q.Ta); store_fe2_signed(w + 16, q.Tb);
+}
+// The same ladder over any table a pointer and an entry stride describe -- the shared fixed-base table in LDS (ladder_kernel<ENDO, LDS>) or in
+// global memory (the fixed-base items of mixed_queue_kernel): the nibble stream's glue with ladder_endo's addressing.
+template <typename L, typename EF, typename TP> FQ_DEV R1 ladder_endo_nibbles_at(const EndoNibbles& e, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:436-442
+    Proj<1, 1, 1> q4 = start_table<L>(tbl + (e.top & 7) * stride, 0u);
+    if constexpr (EF::ON) q4.Z = ef.get(e.top & 7, 0);
+    R1 Q; Q.X = q4.X; Q.Y = q4.Y; Q.Z = q4.Z; Q.Ta = widen<4>(q4.X); Q.Tb = widen<2>(q4.Y);
+    u32 w[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) w[t] = e.w[t];
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        u32 cur = w[7];
+#pragma unroll
+        for (int t = 7; t > 0; t--) w[t] = w[t - 1];
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            const u32 digit = (cur >> 28) & 7;
+            const u32 neg = (u32)((int32_t)cur >> 31);
+            cur <<= 4;
+            EntryRegs t = load_entry<L>(tbl + digit * stride, neg, digit, ef);
+            Fe2<1> T;
+            dblt_asm(Q.X, Q.Y, Q.Z, T);
+            add_asm(Q, T, t, neg);
+        }
+    }
+    return ladder_result<3>(Q);
 }
 template <int CH = (FQ_CHAIN != 0) ? 1 : 0, bool PRELOAD = false, typename L = LimbSlots, typename EF = NoEF, bool TOUCH = false, typename TP> FQ_DEV R1 ladder_windowed(const WinScalar& w, const TP* tbl, int stride, const EF& ef = EF()) {   // curve4q.py:228-235
     u32 code = win_top_code(w);
@@ -683,6 +715,10 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
             u64 v[4];
             decompose(m, v);
             Q = ladder_endo_nibbles<L, EF, !DH>(recode_nibbles(v), a.scratch, lane_slot * (u32)L::SLOT, ef);      // MUL_*: signed limbs, see the store
+        } else if constexpr (ALGO == ENDO && SRC == LDS && !CT && CH == 3 && FQ_NIBBLE_LADDER) {
+            u64 v[4];
+            decompose(m, v);
+            Q = ladder_endo_nibbles_at<LimbSlots, NoEF>(recode_nibbles(v), lds_table, LDS_ENTRY_U32);
         } else if (ALGO == ENDO) {
             u64 v[4];
             decompose(m, v);
@@ -714,7 +750,7 @@ __global__ __launch_bounds__(BLOCK, ladder_waves(SRC, DH, CT)) void ladder_kerne
                 Q = ladder_windowed<CH, SRC == FUSED || CH == 3, L, EF, SRC == PREBUILT && CH != 3>(w, tbl, L::ENTRY, ef);
             }
         }
-        if (DH && DEFER) {                                    // one inversion per K elements, later
+        if (DH && (DEFER || (FQ_FUSED_DEFER && SRC == FUSED && a.proj != nullptr))) {     // one inversion per K elements, later (FUSED: by a wave-uniform flag, no second instance)
             if (live) {
                 store_proj(a.proj, a.proj_stride, id, Q.X, Q.Y, Q.Z);
                 a.status[id] = st;
@@ -922,9 +958,9 @@ __global__ __launch_bounds__(BLOCK, 1) void mixed_queue_kernel(LadderArgs a, con
         } else {
             u64 v[4];
             decompose(m, v);
-            const EndoDigits e = recode(v);
-            if constexpr (CT) Q = ladder_endo_scan<CH>(e, ScanMem<8, u32>{ a.table, R2_LIMBS });      // wave-uniform addresses
-            else Q = ladder_endo<CH, true, LimbSlots, NoEF>(e, a.table, R2_LIMBS);
+            if constexpr (CT) Q = ladder_endo_scan<CH>(recode(v), ScanMem<8, u32>{ a.table, R2_LIMBS });      // wave-uniform addresses
+            else if constexpr (CH == 3 && FQ_NIBBLE_LADDER) Q = ladder_endo_nibbles_at<LimbSlots, NoEF>(recode_nibbles(v), a.table, R2_LIMBS);
+            else Q = ladder_endo<CH, true, LimbSlots, NoEF>(recode(v), a.table, R2_LIMBS);
         }
         if (live) {
             u64 o[20];
