@@ -53,7 +53,7 @@ WORKLOADS = {
     # base: 55 072).  The keygen half actually runs the comb (6 DBL + 27 mixed ADD of 7 M: 6 x 272 + 27 x 336 = 10 704 units
     # + its share of an inversion ~ 400), so alg_mads_run = 11 104 + 55 072 is the figure comparable with the executed one.
     "cfg4": dict(batch=1 << 19, steps=60, bytes=2 * 161, alg_mads=47_616 + 55_072, alg_mads_run=11_104 + 55_072, mads=22_500 + 97_600 + 6_800, seed=40002,
-                 kernel_name="comb_kernel + ladder_kernel<ENDO,FUSED,DH,DEFER> + normalize_kernel<8>",
+                 kernel_name="comb_kernel + ladder_kernel<ENDO,FUSED,DH> + 2 x normalize_kernel<8>",
                  unit="exchange = DH_endo(a, DH_endo(b, G)): two DH_core evaluations",
                  text="BASELINE.json configs[3]: 2^22 dh_exchange over 8 GPUs = 2^19 DH_endo(a, DH_endo(b,G)) per GPU, affine in/out"),
     "cfg5": dict(batch=1 << 17, steps=300, bytes=(192 + 352) // 2, alg_mads=(41_984 + 49_440) // 2, mads=(83_300 + 97_600) // 2, seed=50002,
