@@ -422,8 +422,13 @@ class Bench:
         elapsed = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1) / max(1, steps)      # average launch duration, inter-launch gaps included
         clock = None
+        c = None
         if bracket:
-            c = self.eng.diag_clock_end()
+            try:
+                c = self.eng.diag_clock_end()
+            except Exception as exc:                 # a diagnostic must never cost the run its line: no clock, no cycles_per_unit
+                print("bench.py: clock bracket unavailable (%s)" % exc, file=sys.stderr)
+        if c is not None:
             # the window must be the timed region and nothing else: within 2 % + 0.2 ms of the events' span
             span_ms = kernel_ms * steps
             covered = c["window_us"] * 1e-3 / span_ms if span_ms > 0 else 0.0
