@@ -73,13 +73,11 @@ def test_the_shipped_library_keeps_every_call_sequence_intact(tmp_path):
     from fourq_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("library not built")
-    lib = tmp_path / "lib.so"
-    lib.write_bytes(open(_lib.LIB_PATH, "rb").read())
-    subprocess.run([os.path.join(place_asm.LLVM, "llvm-objdump"), "--offloading", str(lib)], capture_output=True, check=True, cwd=tmp_path)
-    objs = [p for p in tmp_path.iterdir() if p.name.endswith("gfx950")]
+    objs = place_asm.code_objects(_lib.LIB_PATH, str(tmp_path))          # compressed offload bundles since round 6: unpacked here
     assert len(objs) == 4                          # one code object per translation unit
     for o in objs:
-        place_asm.check_pc_relative(str(o))
+        assert open(o, "rb").read(4) == b"\x7fELF"
+        place_asm.check_pc_relative(o)
 
 
 def test_the_shipped_build_was_placed():
