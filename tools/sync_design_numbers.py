@@ -108,8 +108,13 @@ def runs_sentence(d):
     return "; ".join("%s at %.0f MHz = %.2f cycles per element" % (e8(r["value"]), r["clock"]["in_kernel_mhz"], r["cycles_per_unit"]) for r in runs)
 
 
+PINNED_ROUND = None          # --check: the driver's record the committed documents NAME (BENCH_rNN), not whichever is newest on disk
+
+
 def driver_record():
-    """(round number, parsed line) of the newest BENCH_rNN.json at the repo root that the driver could parse, or None."""
+    """(round number, parsed line) of the newest BENCH_rNN.json at the repo root that the driver could parse, or None.  Under --check the
+    record is the one the documents were generated from: the driver drops BENCH_rNN.json of THIS round into the tree after the last commit,
+    and the committed documents cannot quote a file that did not exist yet (a note on stderr says so; the check still passes)."""
     best = None
     for path in glob.glob(os.path.join(ROOT, "BENCH_r*.json")):
         m = re.search(r"BENCH_r(\d+)\.json$", path)
@@ -118,8 +123,18 @@ def driver_record():
                 rec = json.load(fh)
         except (OSError, ValueError):
             continue
-        if m and isinstance(rec.get("parsed"), dict) and "value" in rec["parsed"] and (best is None or int(m.group(1)) > best[0]):
-            best = (int(m.group(1)), rec["parsed"])
+        if not (m and isinstance(rec.get("parsed"), dict) and "value" in rec["parsed"]):
+            continue
+        rnd = int(m.group(1))
+        if PINNED_ROUND is not None:
+            if rnd == PINNED_ROUND:
+                return (rnd, rec["parsed"])
+            if rnd > PINNED_ROUND:
+                print("note: BENCH_r%02d.json is newer than the record the documents quote (BENCH_r%02d): run tools/sync_design_numbers.py to quote it"
+                      % (rnd, PINNED_ROUND), file=sys.stderr)
+            continue
+        if best is None or rnd > best[0]:
+            best = (rnd, rec["parsed"])
     return best
 
 
@@ -160,6 +175,10 @@ def main(argv):
         d = json.load(fh)
     check = "--check" in argv
     bad = []
+    if check:                                    # pin the driver's record to the one the committed documents name
+        global PINNED_ROUND
+        m = re.search(r"BENCH_r(\d+)\.json\.parsed", open(os.path.join(ROOT, "DESIGN.md")).read())
+        PINNED_ROUND = int(m.group(1)) if m else None
     for path, block in (("DESIGN.md", design_block(d)), ("README.md", readme_block(d))):
         full = os.path.join(ROOT, path)
         text = open(full).read()
